@@ -1,0 +1,180 @@
+/* sac_hip.h -- C ABI of libsac_hip.so: the MI355X-native SAC training inner loop.
+ *
+ * Drop-in boundary for the hot path of jeremy29tien/robosuite-benchmark:
+ *   replay_buffer.random_batch(B)  ->  trainer.train(batch)
+ * as driven by  /root/reference/util/rlkit_custom.py:233-240.  The reference has no FFI
+ * (pure Python duck typing); each entry point below names the
+ * reference interface it replaces.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; sac_last_error() gives the text
+ *     of the last error on the calling thread.  The library never aborts the process.
+ *   - the library owns all device memory behind the opaque handles; the caller owns every
+ *     host buffer passed in or out.  Host buffers are plain (pageable) memory; the library
+ *     stages them through its own pinned buffers.
+ *   - a handle is bound to one GPU and one HIP stream; handles are not thread-safe, distinct
+ *     handles are independent.
+ *   - all floating point is IEEE fp32; sampled indices are int64 (NumPy's default dtype).
+ */
+#ifndef SAC_HIP_H
+#define SAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sac_buffer sac_buffer_t;
+typedef struct sac_trainer sac_trainer_t;
+
+const char *sac_last_error(void);
+/* number of visible GPUs (0 when there is none: every create call then fails loudly) */
+int sac_device_count(void);
+const char *sac_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Replay buffer in HBM, structure-of-arrays fp32.
+ * Replaces rlkit EnvReplayBuffer / SimpleReplayBuffer as constructed at
+ * /root/reference/util/rlkit_utils.py:139-142 and used at
+ * /root/reference/util/rlkit_custom.py:207,230 (add_paths), :235-236 (random_batch),
+ * :250-253 (get_diagnostics -> 'size').
+ * ------------------------------------------------------------------------------------------ */
+int sac_buffer_create(sac_buffer_t **out, int64_t capacity, int obs_dim, int act_dim, int device);
+int sac_buffer_destroy(sac_buffer_t *buf);
+
+/* add_paths / add_sample: append n transitions at the ring head (top = (top+1) % capacity,
+ * size = min(size+1, capacity)).  Row-major host arrays: obs (n,O) act (n,A) rew (n) next_obs (n,O)
+ * term (n) uint8 (the reference's terminal dtype).  fp32 here == the reference's float64 storage
+ * followed by np_to_pytorch_batch's float32 cast.  The _f64 form takes the reference's native
+ * float64 arrays and rounds to fp32 on the way in. */
+int sac_buffer_add(sac_buffer_t *buf, int64_t n, const float *obs, const float *act, const float *rew,
+                   const float *next_obs, const uint8_t *term);
+int sac_buffer_add_f64(sac_buffer_t *buf, int64_t n, const double *obs, const double *act, const double *rew,
+                       const double *next_obs, const uint8_t *term);
+int64_t sac_buffer_size(const sac_buffer_t *buf);      /* 'replay_buffer/size' */
+int64_t sac_buffer_top(const sac_buffer_t *buf);
+int64_t sac_buffer_capacity(const sac_buffer_t *buf);
+
+/* The global NumPy legacy stream (np.random.seed at /root/reference/scripts/train.py:112) as the
+ * replay buffer consumes it.  State layout = np.random.get_state(): key[624] + pos.  Round-tripping
+ * the state keeps host NumPy consumers (env resets between training blocks) coherent. */
+int sac_rng_seed(sac_buffer_t *buf, uint32_t seed);
+int sac_rng_get_state(sac_buffer_t *buf, uint32_t key[624], int32_t *pos);
+int sac_rng_set_state(sac_buffer_t *buf, const uint32_t key[624], int32_t pos);
+
+/* np.random.randint(0, size, batch) drawn n_batches times on the device, bit-exact with NumPy
+ * including rejected draws and the generator state afterwards.  idx_out (host, n_batches*batch
+ * int64) may be NULL: indices then stay on the device for sac_gather_sampled / sac_train_loop. */
+int sac_sample_indices(sac_buffer_t *buf, int batch, int64_t n_batches, int64_t *idx_out);
+
+/* random_batch(batch): sample + gather + copy out.  Outputs are host arrays shaped like the
+ * reference's dict entries after np_to_pytorch_batch: observations (B,O), actions (B,A),
+ * rewards (B,1), terminals (B,1), next_observations (B,O), all fp32.  idx_out may be NULL. */
+int sac_random_batch(sac_buffer_t *buf, int batch, float *obs, float *act, float *rew, float *term,
+                     float *next_obs, int64_t *idx_out);
+/* the gather half alone, for caller-supplied indices (parity tests, prioritised variants) */
+int sac_gather(sac_buffer_t *buf, const int64_t *idx, int batch, float *obs, float *act, float *rew,
+               float *term, float *next_obs);
+
+/* Device-side batched form used for measurement: draws n_batches index vectors and gathers all
+ * of them into contiguous minibatch slots in HBM in ONE gather launch; nothing is copied to the
+ * host.  kernel_ms (may be NULL) receives {index kernel ms, gather kernel ms} from HIP events on
+ * the handle's stream. */
+int sac_sample_gather_device(sac_buffer_t *buf, int batch, int64_t n_batches, float kernel_ms[2]);
+/* copy slot s of the last sac_sample_gather_device back to the host (tests) */
+int sac_read_slot(sac_buffer_t *buf, int64_t slot, float *obs, float *act, float *rew, float *term,
+                  float *next_obs, int64_t *idx_out);
+
+/* ------------------------------------------------------------------------------------------
+ * SAC trainer.  Replaces rlkit SACTrainer (+ TorchTrainer.train, np_to_pytorch_batch,
+ * ptu.soft_update_from_to) as constructed at /root/reference/util/rlkit_utils.py:98-106 with the
+ * kwargs of /root/reference/scripts/train.py:29-37 and driven at
+ * /root/reference/util/rlkit_custom.py:238 (train), :258 (get_diagnostics), :63/:70 (snapshot).
+ * Networks: FlattenMlp x4 (rlkit_utils.py:64-83) and TanhGaussianPolicy (:92-96).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sac_config {
+    int32_t obs_dim, act_dim;
+    int32_t hidden;              /* both hidden layers; 256 in every shipped variant.json */
+    int32_t batch;               /* algorithm_kwargs.batch_size */
+    float discount;              /* trainer_kwargs.discount */
+    float reward_scale;          /* trainer_kwargs.reward_scale */
+    float policy_lr, qf_lr;      /* trainer_kwargs.policy_lr / qf_lr (alpha uses policy_lr) */
+    float soft_target_tau;       /* trainer_kwargs.soft_target_tau */
+    int32_t target_update_period;
+    int32_t use_automatic_entropy_tuning;
+    float target_entropy;        /* NaN => -act_dim (rlkit default) */
+    uint64_t noise_seed;         /* device counter-based N(0,1) stream for rsample */
+    int32_t device;
+    int32_t reserved;
+} sac_config_t;
+
+enum { SAC_NET_POLICY = 0, SAC_NET_QF1 = 1, SAC_NET_QF2 = 2, SAC_NET_TARGET_QF1 = 3, SAC_NET_TARGET_QF2 = 4 };
+
+/* diagnostics vector written per step; names = the 'trainer/...' columns of progress.csv
+ * (/root/reference/runs/.../progress.csv:1) plus the optimised actor loss. */
+enum {
+    SAC_D_QF1_LOSS = 0, SAC_D_QF2_LOSS, SAC_D_POLICY_LOSS /* logged: mean(log_pi - q_new) */,
+    SAC_D_ACTOR_LOSS /* optimised: mean(alpha*log_pi - q_new) */,
+    SAC_D_Q1_MEAN, SAC_D_Q1_STD, SAC_D_Q1_MAX, SAC_D_Q1_MIN,
+    SAC_D_Q2_MEAN, SAC_D_Q2_STD, SAC_D_Q2_MAX, SAC_D_Q2_MIN,
+    SAC_D_QT_MEAN, SAC_D_QT_STD, SAC_D_QT_MAX, SAC_D_QT_MIN,
+    SAC_D_LOGPI_MEAN, SAC_D_LOGPI_STD, SAC_D_LOGPI_MAX, SAC_D_LOGPI_MIN,
+    SAC_D_MU_MEAN, SAC_D_MU_STD, SAC_D_MU_MAX, SAC_D_MU_MIN,
+    SAC_D_LOGSTD_MEAN, SAC_D_LOGSTD_STD, SAC_D_LOGSTD_MAX, SAC_D_LOGSTD_MIN,
+    SAC_D_ALPHA, SAC_D_ALPHA_LOSS,
+    SAC_DIAG_N = 32
+};
+
+int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg);
+int sac_trainer_destroy(sac_trainer_t *t);
+
+/* flat fp32 parameter vector of one net, nn.Linear layout (W (out,in) row-major, then b):
+ *   Q nets : fc0.W fc0.b fc1.W fc1.b last_fc.W last_fc.b
+ *   policy : fc0.W fc0.b fc1.W fc1.b last_fc.W last_fc.b last_fc_log_std.W last_fc_log_std.b */
+int64_t sac_param_count(const sac_trainer_t *t, int net);
+int sac_set_params(sac_trainer_t *t, int net, const float *flat, int64_t n);
+int sac_get_params(sac_trainer_t *t, int net, float *flat, int64_t n);
+/* Adam state of the three trained nets (same flat layout) + step count; the reference's snapshot
+ * omits these (SURVEY.md section 5 "Checkpoint / resume"), true resume needs them. */
+int sac_set_opt_state(sac_trainer_t *t, int net, const float *exp_avg, const float *exp_avg_sq, int64_t n);
+int sac_get_opt_state(sac_trainer_t *t, int net, float *exp_avg, float *exp_avg_sq, int64_t n);
+/* scalars[6] = {log_alpha, alpha_exp_avg, alpha_exp_avg_sq, adam_step_count, n_train_steps_total, alpha} */
+int sac_set_scalars(sac_trainer_t *t, const double scalars[6]);
+int sac_get_scalars(sac_trainer_t *t, double scalars[6]);
+
+/* trainer.train(np_batch) == np_to_pytorch_batch + train_from_torch: ONE gradient step on a
+ * caller-supplied batch (host fp32, shapes as sac_random_batch writes them).  eps1/eps2 (B,A) are
+ * the N(0,1) draws of the two rsample() calls (policy on obs, then on next_obs); NULL => the
+ * device counter-based stream.  diag (SAC_DIAG_N floats, may be NULL) receives this step's stats. */
+int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *rew, const float *term,
+             const float *next_obs, const float *eps1, const float *eps2, float *diag);
+
+/* The whole hot loop of rlkit_custom.py:234-238 on the device:
+ *   for _ in range(n_steps): batch = buffer.random_batch(B); trainer.train(batch)
+ * Indices for all n_steps are drawn first (same stream consumption as n_steps random_batch calls:
+ * nothing else touches np.random or the buffer inside the loop), gathered into HBM slots, then the
+ * steps run back to back with no host round trip.  diag_first / diag_last (may be NULL) receive the
+ * diagnostics of the first and last step (the reference logs the first step of each epoch). */
+int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *diag_first, float *diag_last);
+
+/* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop, and
+ * per-kernel-family device time accumulated over it (names via sac_kernel_name). */
+int sac_sync(sac_trainer_t *t);
+int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms);
+
+/* test access to intermediates of the last step: name in {"a_new","log_pi","mu","log_std","q1","q2",
+ * "q_target","q1_new","q2_new","a_next","log_pi_next","g_policy","g_qf1","g_qf2"} (g_* = flat
+ * gradient in the sac_get_params layout).  Returns the element count, <0 on error. */
+int64_t sac_debug_fetch(sac_trainer_t *t, const char *name, float *out, int64_t cap);
+
+/* policy.get_action(obs) on the HOST with weights mirrored from the device (acting path,
+ * /root/reference/util/rlkit_custom.py:437; MakeDeterministic => tanh(mean)).
+ * eps (A floats) may be NULL when deterministic. */
+int sac_policy_mirror(sac_trainer_t *t);
+int sac_policy_act(sac_trainer_t *t, const float *obs, int deterministic, const float *eps, float *act);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAC_HIP_H */

@@ -1,0 +1,495 @@
+// HBM replay buffer: SoA fp32 storage, device MT19937 index generation (bit-exact with NumPy's
+// legacy np.random.randint) and the LDS-staged row gather into contiguous minibatch slots.
+//
+// Replaces rlkit EnvReplayBuffer (call sites /root/reference/util/rlkit_utils.py:139-142,
+// /root/reference/util/rlkit_custom.py:207,230,235-236).  Index algorithm: SURVEY.md Appendix B.
+#include "sac_common.h"
+
+#include <cstring>
+#include <vector>
+
+namespace sac {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+const char *last_error() { return g_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------
+// k_mt_randint: ONE wave walks the MT19937 stream in order.  The twist is wave-synchronous
+// (624 words = 10 passes of 64 lanes; element i needs old mt[i+1] and mt[i+397] or new mt[i-227],
+// both satisfied by ascending 64-wide passes).  Tempering, masking and rejection are lane-parallel;
+// accepted draws are compacted in draw order with a ballot prefix, so output j is exactly the j-th
+// accepted draw and the stream stops right after the draw that produced the last output.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, uint32_t mask, int64_t count,
+                                                   int64_t *__restrict__ out) {
+    __shared__ uint32_t mt[MT_N];
+    __shared__ int s_newpos;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < MT_N; i += 64) mt[i] = st->mt[i];
+    int pos = st->pos;
+    __syncthreads();
+    int64_t produced = 0;
+    while (produced < count) {
+        if (pos >= MT_N) {
+            for (int b = 0; b < MT_N; b += 64) {
+                const int i = b + lane;
+                uint32_t nv = 0;
+                if (i < MT_N) {
+                    const uint32_t cur = mt[i];
+                    const uint32_t nxt = mt[i + 1 == MT_N ? 0 : i + 1];
+                    const uint32_t far = mt[i + MT_M < MT_N ? i + MT_M : i + MT_M - MT_N];
+                    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+                    nv = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+                }
+                __syncthreads();          // all lanes have read before anyone writes
+                if (i < MT_N) mt[i] = nv;
+                __syncthreads();
+            }
+            pos = 0;
+        }
+        for (int base = pos; base < MT_N; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < MT_N;
+            uint32_t y = valid ? mt[i] : 0u;
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= y >> 18;
+            const uint32_t v = y & mask;
+            const bool ok = valid && (v <= rng);
+            const unsigned long long bal = __ballot(ok);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            const int total = __popcll(bal);
+            const int64_t slot = produced + before;
+            if (ok && slot < count) out[slot] = (int64_t)v;
+            if (produced + total >= count) {
+                if (ok && slot == count - 1) s_newpos = i + 1;
+                __syncthreads();
+                pos = s_newpos;
+                produced = count;
+                break;
+            }
+            produced += total;
+            pos = (base + 64 < MT_N) ? base + 64 : MT_N;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < MT_N; i += 64) st->mt[i] = mt[i];
+    if (lane == 0) st->pos = pos;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gather: one 256-thread workgroup moves one 16-row block of one minibatch slot.
+//   HBM rows (16-B aligned, padded stride) --dwordx4--> LDS tile --dwordx4--> contiguous slot.
+// The LDS tile lets the unpadded (B,O) output be written as full 16-B-per-lane coalesced stores
+// and lets the same rows be re-emitted feature-major (saT[KQ][B]) for the weight-gradient kernel.
+// ------------------------------------------------------------------------------------------
+template <typename T4>
+__device__ inline T4 ld16(const float *p) { return *reinterpret_cast<const T4 *>(p); }
+
+__global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__restrict__ idx, int B,
+                                                int64_t n_blocks_total, float *__restrict__ slots,
+                                                SlotLayout L, int write_saT) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Ost = rv.Ost, Ast = rv.Ast, O = rv.O, A = rv.A;
+    float *t_obs = lds;                       // [16][Ost]
+    float *t_nobs = t_obs + RB * Ost;         // [16][Ost]
+    float *t_act = t_nobs + RB * Ost;         // [16][Ast]
+    __shared__ int64_t s_idx[RB];
+    const int tid = threadIdx.x;
+    const int blocks_per_slot = B / RB;
+    for (int64_t blk = blockIdx.x; blk < n_blocks_total; blk += gridDim.x) {
+        const int64_t slot = blk / blocks_per_slot;
+        const int row0 = (int)(blk % blocks_per_slot) * RB;
+        float *S = slots + slot * L.slot_floats;
+        __syncthreads();                      // previous iteration's LDS readers are done
+        if (tid < RB) s_idx[tid] = idx[slot * B + row0 + tid];
+        __syncthreads();
+        // ---- HBM -> LDS (16 B per lane) ----
+        const int oc = Ost >> 2, ac = Ast >> 2;          // 16-B chunks per row
+        for (int c = tid; c < RB * oc; c += 256) {
+            const int r = c / oc, q = c - r * oc;
+            const int64_t src = s_idx[r] * (int64_t)Ost + 4 * q;
+            *reinterpret_cast<float4 *>(t_obs + r * Ost + 4 * q) = ld16<float4>(rv.obs + src);
+            *reinterpret_cast<float4 *>(t_nobs + r * Ost + 4 * q) = ld16<float4>(rv.nobs + src);
+        }
+        for (int c = tid; c < RB * ac; c += 256) {
+            const int r = c / ac, q = c - r * ac;
+            *reinterpret_cast<float4 *>(t_act + r * Ast + 4 * q) =
+                ld16<float4>(rv.act + s_idx[r] * (int64_t)Ast + 4 * q);
+        }
+        if (tid < RB) {
+            S[L.off_rew + row0 + tid] = rv.rew[s_idx[tid]];
+        } else if (tid < 2 * RB) {
+            S[L.off_term + row0 + tid - RB] = rv.term[s_idx[tid - RB]];
+        }
+        __syncthreads();
+        // ---- LDS -> contiguous row-major slot (16*O floats = 64*O bytes, 16-B aligned) ----
+        {
+            float *dst = S + L.off_obs + (int64_t)row0 * O;
+            float *dstn = S + L.off_nobs + (int64_t)row0 * O;
+            const int n4 = (RB * O) >> 2;
+            for (int c = tid; c < n4; c += 256) {
+                float4 a, b;
+                float *pa = &a.x, *pb = &b.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * c + j;
+                    const int r = e / O, k = e - r * O;
+                    pa[j] = t_obs[r * Ost + k];
+                    pb[j] = t_nobs[r * Ost + k];
+                }
+                *reinterpret_cast<float4 *>(dst + 4 * c) = a;
+                *reinterpret_cast<float4 *>(dstn + 4 * c) = b;
+            }
+            float *dsta = S + L.off_act + (int64_t)row0 * A;
+            const int a4 = (RB * A) >> 2;
+            for (int c = tid; c < a4; c += 256) {
+                float4 a;
+                float *pa = &a.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * c + j;
+                    const int r = e / A, k = e - r * A;
+                    pa[j] = t_act[r * Ast + k];
+                }
+                *reinterpret_cast<float4 *>(dsta + 4 * c) = a;
+            }
+        }
+        // ---- LDS -> feature-major saT[f][row0 .. row0+15] ----
+        if (write_saT) {
+            float *T = S + L.off_saT;
+            for (int c = tid; c < (O + A) * 4; c += 256) {
+                const int f = c >> 2, q = c & 3;
+                float4 v;
+                float *pv = &v.x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * q + j;
+                    pv[j] = (f < O) ? t_obs[r * Ost + f] : t_act[r * Ast + (f - O)];
+                }
+                *reinterpret_cast<float4 *>(T + (int64_t)f * B + row0 + 4 * q) = v;
+            }
+        }
+    }
+}
+
+int ensure_stage(sac_buffer *b, size_t bytes) {
+    if (b->stage_bytes >= bytes) return 0;
+    if (b->h_stage) SAC_HIP(hipHostFree(b->h_stage));
+    b->h_stage = nullptr;
+    b->stage_bytes = 0;
+    SAC_HIP(hipHostMalloc(&b->h_stage, bytes, hipHostMallocDefault));
+    b->stage_bytes = bytes;
+    return 0;
+}
+
+int ensure_idx(sac_buffer *b, int64_t n) {
+    if (b->idx_cap >= n) return 0;
+    if (b->d_idx) SAC_HIP(hipFree(b->d_idx));
+    b->d_idx = nullptr;
+    b->idx_cap = 0;
+    SAC_HIP(hipMalloc(&b->d_idx, sizeof(int64_t) * n));
+    b->idx_cap = n;
+    return 0;
+}
+
+int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
+    SlotLayout L = make_slot_layout(B, b->O, b->A);
+    const int64_t need = L.slot_floats * n_slots;
+    if (b->slots_cap < need) {
+        if (b->d_slots) SAC_HIP(hipFree(b->d_slots));
+        b->d_slots = nullptr;
+        b->slots_cap = 0;
+        SAC_HIP(hipMalloc(&b->d_slots, sizeof(float) * need));
+        // padding rows of saT (features >= O+A) are contracted by the weight-gradient kernel: keep them 0
+        SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
+        b->slots_cap = need;
+    } else if (b->slot.B != B) {
+        SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
+    }
+    b->slot = L;
+    b->n_slots = n_slots;
+    return 0;
+}
+
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches) {
+    const int64_t count = (int64_t)batch * n_batches;
+    SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
+    SAC_REQUIRE(b->size - 1 <= 0xffffffffLL, "replay buffers above 2^32 slots are not supported");
+    if (ensure_idx(b, count)) return -1;
+    const uint32_t rng = (uint32_t)(b->size - 1);
+    if (rng == 0) {     // NumPy: no draws consumed, all zeros
+        SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * count, b->stream));
+        return 0;
+    }
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, b->d_idx);
+    SAC_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
+                  const SlotLayout &L, int write_saT) {
+    SAC_REQUIRE(batch > 0 && batch % RB == 0, "batch size %d must be a positive multiple of %d", batch, RB);
+    const int64_t nblk = (int64_t)(batch / RB) * n_batches;
+    const int grid = (int)(nblk < 16384 ? nblk : 16384);
+    const size_t lds = sizeof(float) * (size_t)(2 * RB * b->Ost + RB * b->Ast);
+    SAC_REQUIRE(lds <= 160 * 1024 - 256, "observation rows too wide for the gather tile (%zu B LDS)", lds);
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), lds, b->stream, b->view(), d_idx, batch, nblk, d_slots, L,
+                       write_saT);
+    SAC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace sac
+
+using namespace sac;
+
+// one contiguous ring segment [at, at+n) <- staged rows
+template <typename Src>
+static int add_segment(sac_buffer *b, int64_t at, int64_t n, const Src *obs, const Src *act, const Src *rew,
+                       const Src *nobs, const uint8_t *term) {
+    const int O = b->O, A = b->A, Ost = b->Ost, Ast = b->Ast;
+    const int64_t CH = 16384;
+    const size_t per_row = sizeof(float) * (size_t)(2 * Ost + Ast + 2);
+    if (ensure_stage(b, per_row * CH)) return -1;
+    for (int64_t done = 0; done < n; done += CH) {
+        const int64_t m = (n - done < CH) ? n - done : CH;
+        float *so = (float *)b->h_stage, *sn = so + m * Ost, *sa = sn + m * Ost, *sr = sa + m * Ast, *st = sr + m;
+        for (int64_t i = 0; i < m; ++i) {
+            const Src *po = obs + (done + i) * O, *pn = nobs + (done + i) * O, *pa = act + (done + i) * A;
+            for (int k = 0; k < O; ++k) { so[i * Ost + k] = (float)po[k]; sn[i * Ost + k] = (float)pn[k]; }
+            for (int k = O; k < Ost; ++k) { so[i * Ost + k] = 0.f; sn[i * Ost + k] = 0.f; }
+            for (int k = 0; k < A; ++k) sa[i * Ast + k] = (float)pa[k];
+            for (int k = A; k < Ast; ++k) sa[i * Ast + k] = 0.f;
+            sr[i] = (float)rew[done + i];
+            st[i] = term[done + i] ? 1.0f : 0.0f;
+        }
+        const int64_t r0 = at + done;
+        SAC_HIP(hipMemcpyAsync(b->obs + r0 * Ost, so, sizeof(float) * m * Ost, hipMemcpyHostToDevice, b->stream));
+        SAC_HIP(hipMemcpyAsync(b->nobs + r0 * Ost, sn, sizeof(float) * m * Ost, hipMemcpyHostToDevice, b->stream));
+        SAC_HIP(hipMemcpyAsync(b->act + r0 * Ast, sa, sizeof(float) * m * Ast, hipMemcpyHostToDevice, b->stream));
+        SAC_HIP(hipMemcpyAsync(b->rew + r0, sr, sizeof(float) * m, hipMemcpyHostToDevice, b->stream));
+        SAC_HIP(hipMemcpyAsync(b->term + r0, st, sizeof(float) * m, hipMemcpyHostToDevice, b->stream));
+        SAC_HIP(hipStreamSynchronize(b->stream));   // staging buffer is reused
+    }
+    return 0;
+}
+
+template <typename Src>
+static int add_impl(sac_buffer *b, int64_t n, const Src *obs, const Src *act, const Src *rew, const Src *nobs,
+                    const uint8_t *term) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    SAC_REQUIRE(n >= 0 && obs && act && rew && nobs && term, "bad arguments to sac_buffer_add");
+    SAC_HIP(hipSetDevice(b->device));
+    const int O = b->O, A = b->A;
+    int64_t i = 0;
+    if (n > b->capacity) {      // only the last `capacity` samples survive; keep ring arithmetic exact
+        const int64_t skip = n - b->capacity;
+        b->top = (b->top + skip) % b->capacity;
+        b->size = b->capacity;
+        i = skip;
+    }
+    while (i < n) {
+        const int64_t room = b->capacity - b->top;
+        const int64_t m = (n - i < room) ? n - i : room;
+        if (add_segment<Src>(b, b->top, m, obs + i * O, act + i * A, rew + i, nobs + i * O, term + i)) return -1;
+        b->top = (b->top + m) % b->capacity;
+        b->size = (b->size + m < b->capacity) ? b->size + m : b->capacity;
+        i += m;
+    }
+    return 0;
+}
+
+extern "C" {
+
+const char *sac_last_error(void) { return sac::last_error(); }
+const char *sac_version(void) { return "sac_hip 0.1 (gfx950)"; }
+
+int sac_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sac_buffer_create(sac_buffer_t **out, int64_t capacity, int obs_dim, int act_dim, int device) {
+    SAC_REQUIRE(out != nullptr, "null out pointer");
+    *out = nullptr;
+    SAC_REQUIRE(capacity > 0 && obs_dim > 0 && act_dim > 0, "bad replay buffer shape (%lld, %d, %d)",
+                (long long)capacity, obs_dim, act_dim);
+    SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
+    SAC_HIP(hipSetDevice(device));
+    sac_buffer *b = new sac_buffer();
+    b->device = device;
+    b->capacity = capacity;
+    b->O = obs_dim; b->A = act_dim;
+    b->Ost = round_up(obs_dim, 4); b->Ast = round_up(act_dim, 4);
+    SAC_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    SAC_HIP(hipMalloc(&b->obs, sizeof(float) * capacity * b->Ost));
+    SAC_HIP(hipMalloc(&b->nobs, sizeof(float) * capacity * b->Ost));
+    SAC_HIP(hipMalloc(&b->act, sizeof(float) * capacity * b->Ast));
+    SAC_HIP(hipMalloc(&b->rew, sizeof(float) * capacity));
+    SAC_HIP(hipMalloc(&b->term, sizeof(float) * capacity));
+    SAC_HIP(hipMalloc(&b->d_rng, sizeof(MtState)));
+    for (auto &e : b->ev) SAC_HIP(hipEventCreate(&e));
+    *out = b;
+    return sac_rng_seed(b, 5489u);
+}
+
+int sac_buffer_destroy(sac_buffer_t *b) {
+    if (!b) return 0;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (void *p : {(void *)b->obs, (void *)b->nobs, (void *)b->act, (void *)b->rew, (void *)b->term,
+                    (void *)b->d_rng, (void *)b->d_idx, (void *)b->d_slots})
+        (void)hipFree(p);
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+
+int64_t sac_buffer_size(const sac_buffer_t *b) { return b ? b->size : -1; }
+int64_t sac_buffer_top(const sac_buffer_t *b) { return b ? b->top : -1; }
+int64_t sac_buffer_capacity(const sac_buffer_t *b) { return b ? b->capacity : -1; }
+
+int sac_buffer_add(sac_buffer_t *b, int64_t n, const float *obs, const float *act, const float *rew,
+                   const float *next_obs, const uint8_t *term) {
+    return add_impl<float>(b, n, obs, act, rew, next_obs, term);
+}
+int sac_buffer_add_f64(sac_buffer_t *b, int64_t n, const double *obs, const double *act, const double *rew,
+                       const double *next_obs, const uint8_t *term) {
+    return add_impl<double>(b, n, obs, act, rew, next_obs, term);
+}
+
+int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    SAC_HIP(hipSetDevice(b->device));
+    MtState s;
+    memset(&s, 0, sizeof(s));
+    s.mt[0] = seed;
+    for (int i = 1; i < MT_N; ++i) s.mt[i] = 1812433253u * (s.mt[i - 1] ^ (s.mt[i - 1] >> 30)) + (uint32_t)i;
+    s.pos = MT_N;
+    SAC_HIP(hipMemcpyAsync(b->d_rng, &s, sizeof(s), hipMemcpyHostToDevice, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int sac_rng_get_state(sac_buffer_t *b, uint32_t key[624], int32_t *pos) {
+    SAC_REQUIRE(b && key && pos, "bad arguments to sac_rng_get_state");
+    SAC_HIP(hipSetDevice(b->device));
+    MtState s;
+    SAC_HIP(hipMemcpyAsync(&s, b->d_rng, sizeof(s), hipMemcpyDeviceToHost, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    memcpy(key, s.mt, sizeof(uint32_t) * MT_N);
+    *pos = s.pos;
+    return 0;
+}
+
+int sac_rng_set_state(sac_buffer_t *b, const uint32_t key[624], int32_t pos) {
+    SAC_REQUIRE(b && key && pos >= 0 && pos <= MT_N, "bad arguments to sac_rng_set_state");
+    SAC_HIP(hipSetDevice(b->device));
+    MtState s;
+    memset(&s, 0, sizeof(s));
+    memcpy(s.mt, key, sizeof(uint32_t) * MT_N);
+    s.pos = pos;
+    SAC_HIP(hipMemcpyAsync(b->d_rng, &s, sizeof(s), hipMemcpyHostToDevice, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int sac_sample_indices(sac_buffer_t *b, int batch, int64_t n_batches, int64_t *idx_out) {
+    SAC_REQUIRE(b && batch > 0 && n_batches > 0, "bad arguments to sac_sample_indices");
+    SAC_HIP(hipSetDevice(b->device));
+    if (launch_sample(b, batch, n_batches)) return -1;
+    if (idx_out) {
+        SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch * n_batches, hipMemcpyDeviceToHost,
+                               b->stream));
+    }
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+static int copy_slot_out(sac_buffer *b, int64_t slot, float *obs, float *act, float *rew, float *term,
+                         float *nobs) {
+    const SlotLayout &L = b->slot;
+    const float *S = b->d_slots + slot * L.slot_floats;
+    const int B = L.B;
+    if (obs) SAC_HIP(hipMemcpyAsync(obs, S + L.off_obs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, b->stream));
+    if (act) SAC_HIP(hipMemcpyAsync(act, S + L.off_act, sizeof(float) * B * L.A, hipMemcpyDeviceToHost, b->stream));
+    if (rew) SAC_HIP(hipMemcpyAsync(rew, S + L.off_rew, sizeof(float) * B, hipMemcpyDeviceToHost, b->stream));
+    if (term) SAC_HIP(hipMemcpyAsync(term, S + L.off_term, sizeof(float) * B, hipMemcpyDeviceToHost, b->stream));
+    if (nobs) SAC_HIP(hipMemcpyAsync(nobs, S + L.off_nobs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, b->stream));
+    return 0;
+}
+
+int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *rew, float *term, float *next_obs,
+                     int64_t *idx_out) {
+    SAC_REQUIRE(b && batch > 0, "bad arguments to sac_random_batch");
+    SAC_HIP(hipSetDevice(b->device));
+    if (launch_sample(b, batch, 1)) return -1;
+    if (ensure_slots(b, batch, 1)) return -1;
+    if (launch_gather(b, b->d_idx, batch, 1, b->d_slots, b->slot, 1)) return -1;
+    if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
+    if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int sac_gather(sac_buffer_t *b, const int64_t *idx, int batch, float *obs, float *act, float *rew, float *term,
+               float *next_obs) {
+    SAC_REQUIRE(b && idx && batch > 0, "bad arguments to sac_gather");
+    SAC_HIP(hipSetDevice(b->device));
+    for (int i = 0; i < batch; ++i)
+        SAC_REQUIRE(idx[i] >= 0 && idx[i] < b->size, "index %lld out of range [0, %lld)", (long long)idx[i],
+                    (long long)b->size);
+    if (ensure_idx(b, batch)) return -1;
+    if (ensure_slots(b, batch, 1)) return -1;
+    SAC_HIP(hipMemcpyAsync(b->d_idx, idx, sizeof(int64_t) * batch, hipMemcpyHostToDevice, b->stream));
+    if (launch_gather(b, b->d_idx, batch, 1, b->d_slots, b->slot, 1)) return -1;
+    if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int sac_sample_gather_device(sac_buffer_t *b, int batch, int64_t n_batches, float kernel_ms[2]) {
+    SAC_REQUIRE(b && batch > 0 && n_batches > 0, "bad arguments to sac_sample_gather_device");
+    SAC_HIP(hipSetDevice(b->device));
+    if (ensure_slots(b, batch, n_batches)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[0], b->stream));
+    if (launch_sample(b, batch, n_batches)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[1], b->stream));
+    if (launch_gather(b, b->d_idx, batch, n_batches, b->d_slots, b->slot, 1)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[2], b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    if (kernel_ms) {
+        SAC_HIP(hipEventElapsedTime(&kernel_ms[0], b->ev[0], b->ev[1]));
+        SAC_HIP(hipEventElapsedTime(&kernel_ms[1], b->ev[1], b->ev[2]));
+    }
+    return 0;
+}
+
+int sac_read_slot(sac_buffer_t *b, int64_t slot, float *obs, float *act, float *rew, float *term, float *next_obs,
+                  int64_t *idx_out) {
+    SAC_REQUIRE(b && slot >= 0 && slot < b->n_slots, "slot %lld out of range", (long long)slot);
+    SAC_HIP(hipSetDevice(b->device));
+    if (copy_slot_out(b, slot, obs, act, rew, term, next_obs)) return -1;
+    if (idx_out)
+        SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx + slot * b->slot.B, sizeof(int64_t) * b->slot.B,
+                               hipMemcpyDeviceToHost, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+}  // extern "C"

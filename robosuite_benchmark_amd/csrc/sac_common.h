@@ -1,0 +1,107 @@
+// Shared host/device definitions for libsac_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <cstdio>
+#include <cstdarg>
+
+#include "../../include/sac_hip.h"
+
+namespace sac {
+
+void set_error(const char *fmt, ...);
+
+#define SAC_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            sac::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define SAC_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            sac::set_error(__VA_ARGS__);                                                      \
+            return -2;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+constexpr int RB = 16;            // rows of one row-block (one MFMA 16x16x4 M tile)
+constexpr int MT_N = 624;
+constexpr int MT_M = 397;
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Layout of one minibatch slot in HBM (floats).  Written by the gather kernel, read by the step
+// kernels.  Row-major part == what random_batch returns; saT is the feature-major copy
+// [KQ][B] of cat(obs, act) that the weight-gradient kernel contracts over the batch.
+struct SlotLayout {
+    int B, O, A;
+    int KQ;                       // round_up(O + A, 16)
+    int KQ64;                     // rows allocated for saT: round_up(KQ, 64) (64-wide k strips)
+    int64_t off_obs, off_act, off_rew, off_term, off_nobs, off_saT;
+    int64_t slot_floats;          // multiple of 64 floats (256 B)
+};
+
+static inline SlotLayout make_slot_layout(int B, int O, int A) {
+    SlotLayout L;
+    L.B = B; L.O = O; L.A = A;
+    L.KQ = round_up(O + A, 16);
+    L.KQ64 = round_up(L.KQ, 64);
+    int64_t off = 0;
+    L.off_obs = off;  off += round_up64((int64_t)B * O, 64);
+    L.off_act = off;  off += round_up64((int64_t)B * A, 64);
+    L.off_rew = off;  off += round_up64(B, 64);
+    L.off_term = off; off += round_up64(B, 64);
+    L.off_nobs = off; off += round_up64((int64_t)B * O, 64);
+    L.off_saT = off;  off += (int64_t)L.KQ64 * B;
+    L.slot_floats = round_up64(off, 64);
+    return L;
+}
+
+struct MtState {
+    uint32_t mt[MT_N];
+    int32_t pos;
+    int32_t pad[3];
+};
+
+}  // namespace sac
+
+// device-side view of the replay storage
+struct ReplayView {
+    const float *obs, *act, *rew, *term, *nobs;
+    int O, A, Ost, Ast;           // row strides (floats), multiples of 4
+    int64_t capacity;
+};
+
+struct sac_buffer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t capacity = 0, size = 0, top = 0;
+    int O = 0, A = 0, Ost = 0, Ast = 0;
+    float *obs = nullptr, *act = nullptr, *rew = nullptr, *term = nullptr, *nobs = nullptr;
+    sac::MtState *d_rng = nullptr;
+    // sampled indices + gathered slots of the last batched draw
+    int64_t *d_idx = nullptr; int64_t idx_cap = 0;
+    float *d_slots = nullptr; int64_t slots_cap = 0;      // floats
+    sac::SlotLayout slot{};
+    int64_t n_slots = 0;
+    // pinned staging
+    void *h_stage = nullptr; size_t stage_bytes = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
+};
+
+namespace sac {
+int ensure_stage(sac_buffer *b, size_t bytes);
+int ensure_idx(sac_buffer *b, int64_t n);
+int ensure_slots(sac_buffer *b, int B, int64_t n_slots);
+// launches on b->stream; indices stay in b->d_idx, slots in b->d_slots
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches);
+int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
+                  const SlotLayout &L, int write_saT);
+}  // namespace sac

@@ -1,0 +1,133 @@
+"""Host-side parameter holders with the constructor signatures of rlkit's networks.
+
+Reference call sites: /root/reference/util/rlkit_utils.py:64-83 (4x ``FlattenMlp(input_size,
+output_size, hidden_sizes)``), :92-97 (``TanhGaussianPolicy(obs_dim, action_dim, hidden_sizes)``,
+``MakeDeterministic``).  Layer names (fc0, fc1, last_fc, last_fc_log_std) follow the shipped
+params.pkl.  These objects own numpy parameters; ``SACTrainer`` uploads them to HBM and keeps
+them in sync.  ``.to(device)`` / ``.train(mode)`` are no-ops (rlkit_custom.py:306-312)."""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+
+class _Mlp:
+    def __init__(self, hidden_sizes, output_sizes, input_size, init_w, rs=None):
+        rs = rs or np.random      # rlkit draws its init from the torch global generator; [R]
+        self.input_size, self.hidden_sizes = int(input_size), list(hidden_sizes)
+        self.layers = OrderedDict()
+        d = self.input_size
+        for i, h in enumerate(self.hidden_sizes):
+            bound = 1.0 / math.sqrt(h)      # rlkit fanin_init: size[0] of the (out,in) weight  [R]
+            self.layers[f"fc{i}"] = [rs.uniform(-bound, bound, (h, d)).astype(np.float32),
+                                     np.zeros(h, np.float32)]
+            d = h
+        for name, n_out in output_sizes:
+            self.layers[name] = [rs.uniform(-init_w, init_w, (n_out, d)).astype(np.float32),
+                                 rs.uniform(-init_w, init_w, (n_out,)).astype(np.float32)]
+        self._trainer = None
+
+    # nn.Module look-alikes the epoch loop touches
+    def to(self, device):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def flat(self):
+        return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in self.layers.values()])
+
+    def load_flat(self, vec):
+        vec = np.asarray(vec, dtype=np.float32)
+        off = 0
+        for wb in self.layers.values():
+            for j in range(2):
+                n = wb[j].size
+                wb[j] = vec[off:off + n].reshape(wb[j].shape).copy()
+                off += n
+        assert off == vec.size
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for name, (w, b) in self.layers.items():
+            sd[name + ".weight"], sd[name + ".bias"] = w.copy(), b.copy()
+        return sd
+
+    def as_layer_list(self):
+        return [(w, b) for w, b in self.layers.values()]
+
+
+class FlattenMlp(_Mlp):
+    """``FlattenMlp(input_size=, output_size=, hidden_sizes=)``: cat(inputs, dim=1) -> relu MLP."""
+
+    def __init__(self, hidden_sizes, output_size, input_size, init_w=3e-3, **kwargs):
+        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"))
+
+    def forward_np(self, *inputs):
+        h = np.concatenate(inputs, axis=1).astype(np.float32)
+        names = list(self.layers)
+        for n in names[:-1]:
+            w, b = self.layers[n]
+            h = np.maximum(h @ w.T + b, 0)
+        w, b = self.layers[names[-1]]
+        return h @ w.T + b
+
+
+class TanhGaussianPolicy(_Mlp):
+    """``TanhGaussianPolicy(hidden_sizes=, obs_dim=, action_dim=)``; ``get_action(obs_np)`` returns
+    ``(action, {})`` like rlkit (rlkit_custom.py:437).  Acting runs on the host from this object's
+    parameters, which the trainer refreshes once per training block."""
+
+    LOG_SIG_MAX, LOG_SIG_MIN = 2.0, -20.0
+
+    def __init__(self, hidden_sizes, obs_dim, action_dim, std=None, init_w=1e-3, **kwargs):
+        assert std is None, "fixed-std policies are not used by the benchmark"
+        super().__init__(hidden_sizes, [("last_fc", action_dim), ("last_fc_log_std", action_dim)], obs_dim,
+                         init_w, kwargs.get("rs"))
+        self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
+        self._noise = np.random.RandomState(0)
+
+    def _trunk(self, obs):
+        h = np.asarray(obs, np.float32)
+        for n in list(self.layers)[:-2]:
+            w, b = self.layers[n]
+            h = np.maximum(h @ w.T + b, 0)
+        wm, bm = self.layers["last_fc"]
+        ws, bs = self.layers["last_fc_log_std"]
+        return h @ wm.T + bm, np.clip(h @ ws.T + bs, self.LOG_SIG_MIN, self.LOG_SIG_MAX)
+
+    def get_actions(self, obs_np, deterministic=False):
+        if self._trainer is not None:
+            self._trainer.refresh_host_policy()
+        mean, log_std = self._trunk(obs_np)
+        if deterministic:
+            return np.tanh(mean)
+        eps = self._noise.standard_normal(mean.shape).astype(np.float32)
+        return np.tanh(mean + np.exp(log_std) * eps)
+
+    def get_action(self, obs_np, deterministic=False):
+        return self.get_actions(np.asarray(obs_np)[None], deterministic=deterministic)[0, :], {}
+
+    def reset(self):
+        pass
+
+
+class MakeDeterministic:
+    """``MakeDeterministic(stochastic_policy)``: action = tanh(mean)."""
+
+    def __init__(self, stochastic_policy):
+        self.stochastic_policy = stochastic_policy
+
+    def get_action(self, observation):
+        return self.stochastic_policy.get_action(observation, deterministic=True)
+
+    def reset(self):
+        pass
+
+    def to(self, device):
+        return self
+
+    def train(self, mode=True):
+        return self

@@ -1,0 +1,157 @@
+"""EnvReplayBuffer living in HBM (mirror of rlkit's EnvReplayBuffer / SimpleReplayBuffer).
+
+Reference call sites: /root/reference/util/rlkit_utils.py:139-142 (constructor
+``EnvReplayBuffer(replay_buffer_size, expl_env)``), /root/reference/util/rlkit_custom.py:207,230
+(``add_paths``), :235-236 (``random_batch``), :62,80 (snapshot), :250-253 (``get_diagnostics``)."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+
+
+def _space_dim(space):
+    if hasattr(space, "low"):
+        return int(np.asarray(space.low).size)
+    return int(space)
+
+
+class EnvReplayBuffer:
+    """``EnvReplayBuffer(max_replay_buffer_size, env)``; ``env`` only supplies
+    observation_space / action_space sizes (pass ``obs_dim=`` / ``action_dim=`` instead when
+    there is no env object).  Sampling consumes the NumPy legacy global stream: seed it with
+    ``seed_from_numpy()`` after ``np.random.seed`` (scripts/train.py:112) or ``seed(int)``."""
+
+    def __init__(self, max_replay_buffer_size, env=None, env_info_sizes=None, obs_dim=None, action_dim=None,
+                 device=0):
+        if env is not None:
+            obs_dim = _space_dim(env.observation_space)
+            action_dim = _space_dim(env.action_space)
+        if obs_dim is None or action_dim is None:
+            raise ValueError("EnvReplayBuffer needs an env or obs_dim/action_dim")
+        self.env = env
+        self._observation_dim, self._action_dim = int(obs_dim), int(action_dim)
+        self._max_replay_buffer_size = int(max_replay_buffer_size)
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.sac_buffer_create(C.byref(h), self._max_replay_buffer_size, self._observation_dim,
+                                               self._action_dim, int(device)), "sac_buffer_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.sac_buffer_destroy(h)
+
+    # ---- the np.random global stream ----------------------------------------------------
+    def seed(self, seed: int):
+        _lib.check(self._lib.sac_rng_seed(self._h, int(seed) & 0xFFFFFFFF), "sac_rng_seed")
+
+    def seed_from_numpy(self, rs=None):
+        """Adopt the state of np.random (or a RandomState): sampling then continues that stream."""
+        st = (rs or np.random).get_state()
+        key = np.ascontiguousarray(st[1], dtype=np.uint32)
+        _lib.check(self._lib.sac_rng_set_state(self._h, _lib.ptr(key), int(st[2])), "sac_rng_set_state")
+
+    def sync_to_numpy(self, rs=None):
+        """Write the device stream state back into np.random (host consumers stay coherent)."""
+        key = np.empty(624, dtype=np.uint32)
+        pos = C.c_int32()
+        _lib.check(self._lib.sac_rng_get_state(self._h, _lib.ptr(key), C.byref(pos)), "sac_rng_get_state")
+        (rs or np.random).set_state(("MT19937", key, int(pos.value), 0, 0.0))
+
+    def rng_state(self):
+        key = np.empty(624, dtype=np.uint32)
+        pos = C.c_int32()
+        _lib.check(self._lib.sac_rng_get_state(self._h, _lib.ptr(key), C.byref(pos)), "sac_rng_get_state")
+        return key, int(pos.value)
+
+    # ---- rlkit ReplayBuffer interface ----------------------------------------------------
+    def add_sample(self, observation, action, reward, next_observation, terminal, **kwargs):
+        self.add_block(np.asarray(observation)[None], np.asarray(action)[None], np.asarray([reward]),
+                       np.asarray(next_observation)[None], np.asarray([terminal]))
+
+    def add_block(self, observations, actions, rewards, next_observations, terminals):
+        n = len(observations)
+        t = np.ascontiguousarray(np.asarray(terminals).reshape(n) != 0, dtype=np.uint8)
+        o, a, no = (np.asarray(x) for x in (observations, actions, next_observations))
+        r = np.asarray(rewards).reshape(n)
+        if o.dtype == np.float32 and a.dtype == np.float32 and no.dtype == np.float32:
+            o, a, r, no = map(_lib.f32, (o, a, r, no))
+            fn = self._lib.sac_buffer_add
+        else:   # the reference's native float64 paths
+            o, a, r, no = (np.ascontiguousarray(x, dtype=np.float64) for x in (o, a, r, no))
+            fn = self._lib.sac_buffer_add_f64
+        assert o.shape == (n, self._observation_dim) and a.shape == (n, self._action_dim)
+        _lib.check(fn(self._h, n, _lib.ptr(o), _lib.ptr(a), _lib.ptr(r), _lib.ptr(no), _lib.ptr(t)),
+                   "sac_buffer_add")
+
+    def add_path(self, path):
+        self.add_block(path["observations"], path["actions"], path["rewards"], path["next_observations"],
+                       path["terminals"])
+        self.terminate_episode()
+
+    def add_paths(self, paths):
+        for path in paths:
+            self.add_path(path)
+
+    def terminate_episode(self):
+        pass
+
+    def num_steps_can_sample(self):
+        return int(self._lib.sac_buffer_size(self._h))
+
+    def random_batch(self, batch_size, return_indices=False):
+        B, O, A = int(batch_size), self._observation_dim, self._action_dim
+        obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)
+        act = np.empty((B, A), np.float32)
+        rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        idx = np.empty(B, np.int64)
+        _lib.check(self._lib.sac_random_batch(self._h, B, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
+                                              _lib.ptr(term), _lib.ptr(nobs), _lib.ptr(idx)), "sac_random_batch")
+        batch = dict(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs)
+        return (batch, idx) if return_indices else batch
+
+    def gather(self, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        B, O, A = len(idx), self._observation_dim, self._action_dim
+        obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)
+        act = np.empty((B, A), np.float32)
+        rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        _lib.check(self._lib.sac_gather(self._h, _lib.ptr(idx), B, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
+                                        _lib.ptr(term), _lib.ptr(nobs)), "sac_gather")
+        return dict(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs)
+
+    def sample_indices(self, batch_size, n_batches=1):
+        idx = np.empty(int(batch_size) * int(n_batches), np.int64)
+        _lib.check(self._lib.sac_sample_indices(self._h, int(batch_size), int(n_batches), _lib.ptr(idx)),
+                   "sac_sample_indices")
+        return idx.reshape(int(n_batches), int(batch_size))
+
+    def sample_gather_device(self, batch_size, n_batches):
+        ms = np.zeros(2, np.float32)
+        _lib.check(self._lib.sac_sample_gather_device(self._h, int(batch_size), int(n_batches), _lib.ptr(ms)),
+                   "sac_sample_gather_device")
+        return float(ms[0]), float(ms[1])
+
+    def read_slot(self, slot, batch_size):
+        B, O, A = int(batch_size), self._observation_dim, self._action_dim
+        obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)
+        act = np.empty((B, A), np.float32)
+        rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        idx = np.empty(B, np.int64)
+        _lib.check(self._lib.sac_read_slot(self._h, int(slot), _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
+                                           _lib.ptr(term), _lib.ptr(nobs), _lib.ptr(idx)), "sac_read_slot")
+        return dict(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs), idx
+
+    def get_diagnostics(self):
+        return OrderedDict([("size", self.num_steps_can_sample())])
+
+    def get_snapshot(self):
+        return {}
+
+    def end_epoch(self, epoch):
+        return

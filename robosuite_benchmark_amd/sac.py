@@ -1,0 +1,183 @@
+"""SACTrainer over libsac_hip.so (mirror of rlkit.torch.sac.sac.SACTrainer).
+
+Reference call sites: /root/reference/util/rlkit_utils.py:98-106 (constructor kwargs =
+variant['trainer_kwargs'], scripts/train.py:29-37), /root/reference/util/rlkit_custom.py:238
+(``train(np_batch)``), :258 (``get_diagnostics``), :63,:70 (``get_snapshot``), :306-312
+(``networks``), :291 (``reward_scale``).  Step semantics: SURVEY.md Appendix A."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIAG_NAMES, NET_IDS, SacConfig
+
+
+class SACTrainer:
+    def __init__(self, env=None, policy=None, qf1=None, qf2=None, target_qf1=None, target_qf2=None,
+                 discount=0.99, reward_scale=1.0, policy_lr=1e-3, qf_lr=1e-3, optimizer_class=None,
+                 soft_target_tau=1e-2, target_update_period=1, plotter=None, render_eval_paths=False,
+                 use_automatic_entropy_tuning=True, target_entropy=None, batch_size=None, noise_seed=0,
+                 device=0):
+        assert optimizer_class is None, "only Adam (rlkit's default) is implemented"
+        self.env = env
+        self.policy, self.qf1, self.qf2 = policy, qf1, qf2
+        self.target_qf1, self.target_qf2 = target_qf1, target_qf2
+        self.discount, self.reward_scale = float(discount), float(reward_scale)
+        self.policy_lr, self.qf_lr = float(policy_lr), float(qf_lr)
+        self.soft_target_tau, self.target_update_period = float(soft_target_tau), int(target_update_period)
+        self.use_automatic_entropy_tuning = bool(use_automatic_entropy_tuning)
+        self.obs_dim, self.act_dim = policy.obs_dim, policy.action_dim
+        self.target_entropy = float(-self.act_dim if target_entropy is None else target_entropy)
+        self.noise_seed, self.device = int(noise_seed), int(device)
+        self.eval_statistics = OrderedDict()
+        self._need_to_update_eval_statistics = True
+        self._num_train_steps = 0
+        self._lib = _lib.load()
+        self._h, self._batch = None, None
+        self._host_policy_stale = False
+        policy._trainer = self
+        if batch_size is not None:
+            self._create(int(batch_size))
+
+    # ---- handle management -----------------------------------------------------------------
+    def _create(self, batch):
+        hs = self.policy.hidden_sizes
+        if list(hs) != [256, 256] or list(self.qf1.hidden_sizes) != [256, 256]:
+            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements the benchmark's [256, 256]")
+        cfg = SacConfig(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale, self.policy_lr,
+                        self.qf_lr, self.soft_target_tau, self.target_update_period,
+                        int(self.use_automatic_entropy_tuning), self.target_entropy, self.noise_seed, self.device, 0)
+        h = C.c_void_p()
+        _lib.check(self._lib.sac_trainer_create(C.byref(h), C.byref(cfg)), "sac_trainer_create")
+        state = self._export_state() if self._h else None
+        self._destroy()
+        self._h, self._batch = h, batch
+        if state is None:
+            for name in NET_IDS:
+                self._set_params(name, getattr(self, name).flat())
+        else:
+            self._import_state(state)
+
+    def _destroy(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.sac_trainer_destroy(h)
+
+    def __del__(self):
+        self._destroy()
+
+    def _set_params(self, name, flat):
+        flat = _lib.f32(flat)
+        _lib.check(self._lib.sac_set_params(self._h, NET_IDS[name], _lib.ptr(flat), flat.size), "sac_set_params")
+
+    def _get_params(self, name):
+        n = int(self._lib.sac_param_count(self._h, NET_IDS[name]))
+        out = np.empty(n, np.float32)
+        _lib.check(self._lib.sac_get_params(self._h, NET_IDS[name], _lib.ptr(out), n), "sac_get_params")
+        return out
+
+    def _export_state(self):
+        st = dict(params={k: self._get_params(k) for k in NET_IDS}, opt={})
+        for k in ("policy", "qf1", "qf2"):
+            n = st["params"][k].size
+            m, v = np.empty(n, np.float32), np.empty(n, np.float32)
+            _lib.check(self._lib.sac_get_opt_state(self._h, NET_IDS[k], _lib.ptr(m), _lib.ptr(v), n),
+                       "sac_get_opt_state")
+            st["opt"][k] = (m, v)
+        sc = np.zeros(6, np.float64)
+        _lib.check(self._lib.sac_get_scalars(self._h, _lib.ptr(sc)), "sac_get_scalars")
+        st["scalars"] = sc
+        return st
+
+    def _import_state(self, st):
+        for k, v in st["params"].items():
+            self._set_params(k, v)
+        for k, (m, v) in st["opt"].items():
+            _lib.check(self._lib.sac_set_opt_state(self._h, NET_IDS[k], _lib.ptr(_lib.f32(m)), _lib.ptr(_lib.f32(v)),
+                                                   m.size), "sac_set_opt_state")
+        sc = np.ascontiguousarray(st["scalars"], np.float64)
+        _lib.check(self._lib.sac_set_scalars(self._h, _lib.ptr(sc)), "sac_set_scalars")
+
+    state_dict, load_state_dict = _export_state, _import_state
+
+    # ---- rlkit Trainer interface -------------------------------------------------------------
+    @property
+    def networks(self):
+        return [self.policy, self.qf1, self.qf2, self.target_qf1, self.target_qf2]
+
+    def train(self, np_batch, eps=None):
+        """TorchTrainer.train: np_to_pytorch_batch + train_from_torch (one gradient step)."""
+        self._num_train_steps += 1
+        obs = _lib.f32(np_batch["observations"])
+        B = obs.shape[0]
+        if self._h is None or B != self._batch:
+            self._create(B)
+        act, nobs = _lib.f32(np_batch["actions"]), _lib.f32(np_batch["next_observations"])
+        rew = _lib.f32(np.asarray(np_batch["rewards"]).reshape(B))
+        term = _lib.f32(np.asarray(np_batch["terminals"]).reshape(B))
+        e1 = e2 = None
+        if eps is not None:
+            e1, e2 = _lib.f32(eps[0]), _lib.f32(eps[1])
+        diag = np.empty(_lib.SAC_DIAG_N, np.float32)
+        _lib.check(self._lib.sac_step(self._h, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew), _lib.ptr(term),
+                                      _lib.ptr(nobs), _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(diag)), "sac_step")
+        self._host_policy_stale = True
+        self._record(diag)
+        return diag
+
+    def train_loop(self, replay_buffer, n_steps, batch_size=None):
+        """The fused hot loop of rlkit_custom.py:234-238 (n_steps x {random_batch; train})."""
+        B = int(batch_size or self._batch)
+        if self._h is None or B != self._batch:
+            self._create(B)
+        first, last = np.empty(_lib.SAC_DIAG_N, np.float32), np.empty(_lib.SAC_DIAG_N, np.float32)
+        _lib.check(self._lib.sac_train_loop(self._h, replay_buffer._h, int(n_steps), _lib.ptr(first), _lib.ptr(last)),
+                   "sac_train_loop")
+        self._num_train_steps += int(n_steps)
+        self._host_policy_stale = True
+        self._record(first)
+        return first, last
+
+    def loop_timing_ms(self):
+        v = [C.c_float() for _ in range(4)]
+        _lib.check(self._lib.sac_last_loop_ms(self._h, *[C.byref(x) for x in v]), "sac_last_loop_ms")
+        return dict(total=v[0].value, sample=v[1].value, gather=v[2].value, steps=v[3].value)
+
+    def _record(self, diag):
+        if self._need_to_update_eval_statistics:
+            self._need_to_update_eval_statistics = False
+            for i, name in enumerate(DIAG_NAMES):
+                if name != "Actor Loss":          # not an rlkit column
+                    self.eval_statistics[name] = float(diag[i])
+
+    def get_diagnostics(self):
+        return self.eval_statistics
+
+    def end_epoch(self, epoch):
+        self._need_to_update_eval_statistics = True
+
+    def refresh_host_policy(self):
+        """Mirror the trained policy D2H once per training block (acting stays on the host)."""
+        if self._h is not None and self._host_policy_stale:
+            self.policy.load_flat(self._get_params("policy"))
+            self._host_policy_stale = False
+
+    def sync_networks_to_host(self):
+        for name in NET_IDS:
+            getattr(self, name).load_flat(self._get_params(name))
+        self._host_policy_stale = False
+
+    def get_snapshot(self):
+        if self._h is not None:
+            self.sync_networks_to_host()
+        return dict(policy=self.policy, qf1=self.qf1, qf2=self.qf2, target_qf1=self.target_qf1,
+                    target_qf2=self.target_qf2)
+
+    def debug_fetch(self, name, n):
+        out = np.empty(int(n), np.float32)
+        got = self._lib.sac_debug_fetch(self._h, name.encode(), _lib.ptr(out), out.size)
+        _lib.check(int(got), "sac_debug_fetch")
+        return out[:got]

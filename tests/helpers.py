@@ -1,0 +1,47 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import numpy as np
+
+from oracle.sac_step_torch import RlkitEquivalentSAC, init_sac_params
+
+TASK_DIMS = {"Lift": (42, 7), "Door": (46, 7), "Stack": (55, 7), "TwoArmLift": (89, 14), "Wipe": (379, 6),
+             "TwoArmPegInHole": (73, 12), "TwoArmHandoff": (86, 14)}
+
+
+def synth_transitions(n, O, A, seed=1234, term_frac=0.0, reward_scale=1.0):
+    """SURVEY.md section 8d synthetic data: obs ~ N(0, .5^2), act ~ U(-1,1), rew ~ U(0,1)."""
+    rs = np.random.RandomState(seed)
+    obs = rs.normal(0, 0.5, (n, O)).astype(np.float32)
+    nobs = rs.normal(0, 0.5, (n, O)).astype(np.float32)
+    act = rs.uniform(-1, 1, (n, A)).astype(np.float32)
+    rew = (rs.uniform(0, 1, (n, 1)) * reward_scale).astype(np.float32)
+    term = (rs.uniform(0, 1, (n, 1)) < term_frac).astype(np.uint8)
+    return obs, act, rew, term, nobs
+
+
+def flat_of(layers):
+    return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in layers]).astype(np.float32)
+
+
+def make_pair(O, A, B, seed=3, device=0, **kw):
+    """An oracle and a HIP trainer holding identical parameters."""
+    from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy
+    kw.setdefault("policy_lr", 1e-3)
+    kw.setdefault("qf_lr", 5e-4)
+    kw.setdefault("soft_target_tau", 0.005)
+    kw.setdefault("target_update_period", 5)
+    nets = init_sac_params(O, A, seed=seed)
+    noise_seed = kw.pop("noise_seed", 0)
+    oracle = RlkitEquivalentSAC(nets, A, **kw)
+    pol = TanhGaussianPolicy([256, 256], O, A)
+    qs = [FlattenMlp([256, 256], 1, O + A) for _ in range(4)]
+    pol.load_flat(flat_of(nets["policy"]))
+    for q, name in zip(qs, ("qf1", "qf2", "target_qf1", "target_qf2")):
+        q.load_flat(flat_of(nets[name]))
+    hip = SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=B,
+                     device=device, noise_seed=noise_seed, **kw)
+    return oracle, hip
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))

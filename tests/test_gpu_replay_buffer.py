@@ -1,0 +1,152 @@
+"""GPU parity: HBM replay buffer -- sampled indices bit-exact with NumPy's legacy stream,
+gathered minibatches bit-exact with the reference-shaped host buffer (float64 storage, fancy
+index, float32 cast: rlkit SimpleReplayBuffer.random_batch + np_to_pytorch_batch)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.sac_step_torch import HostReplayBuffer, np_to_f32_batch
+from tests.helpers import synth_transitions
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_buffers(cap, n, O, A, seed=0, term_frac=0.05):
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=seed, term_frac=term_frac)
+    host = HostReplayBuffer(cap, O, A)
+    host.fill_block(obs.astype(np.float64), act.astype(np.float64), rew, term, nobs.astype(np.float64))
+    dev = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)
+    dev.add_block(obs, act, rew, nobs, term)
+    return host, dev
+
+
+def assert_batch_equal(got, want):
+    want = np_to_f32_batch(want)
+    for k in ("observations", "actions", "rewards", "terminals", "next_observations"):
+        assert got[k].dtype == np.float32 and got[k].shape == want[k].shape, k
+        assert np.array_equal(got[k], want[k]), k
+
+
+@pytest.mark.parametrize("seed", [1, 17, 59, 83, 129, 251])
+@pytest.mark.parametrize("size", [1, 2, 3, 3300, 5800, 10_000])
+def test_indices_bit_exact_vs_numpy(seed, size):
+    host, dev = make_buffers(max(size, 16), size, 5, 2, seed=seed)
+    dev.seed(seed)
+    rs = np.random.RandomState(seed)
+    for B in (16, 128, 256, 1024):
+        want = rs.randint(0, size, B)
+        got = dev.sample_indices(B)[0]
+        assert got.dtype == np.int64 and np.array_equal(got, want)
+    # generator state afterwards == NumPy's (future stream identical)
+    tmp = np.random.RandomState(0)
+    dev.sync_to_numpy(tmp)
+    assert np.array_equal(tmp.randint(0, 1 << 30, 2000), rs.randint(0, 1 << 30, 2000))
+
+
+def test_indices_match_golden_fixture():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "index_stream.npz"))
+    for seed in (17, 59, 83, 129, 251):
+        for size in (3300, 5800, 10_000):
+            _, dev = make_buffers(size, size, 3, 2, seed=1)
+            dev.seed(seed)
+            got = dev.sample_indices(256, 4).ravel()
+            assert np.array_equal(got, z[f"s{seed}_n{size}"])
+
+
+def test_full_size_buffer_indices_and_draw_count():
+    """1e6-slot buffer (BASELINE config 2): bit-exact, and 265 draws for the first 256-batch."""
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    N, O, A = 1_000_000, 42, 7
+    dev = EnvReplayBuffer(N, obs_dim=O, action_dim=A)
+    rs0 = np.random.RandomState(5)
+    chunk = 250_000
+    for i in range(N // chunk):
+        o = rs0.normal(0, 0.5, (chunk, O)).astype(np.float32)
+        dev.add_block(o, np.zeros((chunk, A), np.float32), np.zeros(chunk, np.float32), o, np.zeros(chunk, np.uint8))
+    assert dev.num_steps_can_sample() == N
+    dev.seed(17)
+    rs = np.random.RandomState(17)
+    got = dev.sample_indices(256)[0]
+    assert np.array_equal(got, rs.randint(0, N, 256))
+    assert dev.rng_state()[1] == 265
+    z = np.load(os.path.join(ROOT, "tests", "golden", "index_stream.npz"))
+    dev.seed(17)
+    assert np.array_equal(dev.sample_indices(256, 4).ravel(), z["s17_n1000000"])
+    # 1000 steps drawn in one launch == 1000 separate randint calls
+    dev.seed(129)
+    rs = np.random.RandomState(129)
+    want = np.stack([rs.randint(0, N, 256) for _ in range(1000)])
+    assert np.array_equal(dev.sample_indices(256, 1000), want)
+
+
+@pytest.mark.parametrize("O,A", [(42, 7), (46, 7), (89, 14), (379, 6), (3, 1)])
+def test_random_batch_bit_exact_vs_host_buffer(O, A):
+    host, dev = make_buffers(5000, 5000, O, A, seed=3)
+    np.random.seed(17)
+    dev.seed_from_numpy()
+    for B in (16, 128, 256):
+        want, widx = host.random_batch(B)
+        got, gidx = dev.random_batch(B, return_indices=True)
+        assert np.array_equal(gidx, widx)
+        assert_batch_equal(got, want)
+    # hand the stream back to NumPy: host consumers continue coherently
+    ref = np.random.RandomState(17)
+    for B in (16, 128, 256):
+        ref.randint(0, 5000, B)
+    dev.sync_to_numpy()
+    assert np.array_equal(np.random.randint(0, 99, 50), ref.randint(0, 99, 50))
+
+
+def test_gather_given_indices_and_ragged_edges():
+    host, dev = make_buffers(1000, 1000, 42, 7, seed=4)
+    idx = np.array([0, 999, 999, 0, 5, 5, 5, 17] * 2, dtype=np.int64)   # duplicates + both ends
+    got = dev.gather(idx)
+    want = dict(observations=host._obs[idx], actions=host._act[idx], rewards=host._rew[idx],
+                terminals=host._term[idx], next_observations=host._next_obs[idx])
+    assert_batch_equal(got, want)
+    with pytest.raises(RuntimeError):
+        dev.gather(np.array([1000] * 16, dtype=np.int64))
+    with pytest.raises(RuntimeError):
+        dev.random_batch(17)         # not a multiple of the 16-row block
+
+
+def test_ring_semantics_wraparound_and_size_saturation():
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    cap, O, A = 1000, 6, 3
+    host = HostReplayBuffer(cap, O, A)
+    dev = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)
+    with pytest.raises(RuntimeError):
+        dev.random_batch(16)          # empty buffer
+    rs = np.random.RandomState(0)
+    for n in (300, 300, 300, 300, 2500, 1):    # crosses the end, overfills, single add_sample
+        o = rs.normal(size=(n, O)); a = rs.normal(size=(n, A)); r = rs.normal(size=(n, 1))
+        t = (rs.uniform(size=(n, 1)) < 0.1).astype(np.uint8); no = rs.normal(size=(n, O))
+        host.add_block(o, a, r, t, no)
+        dev.add_block(o, a, r, no, t)           # float64 path (the reference's native dtype)
+        assert dev.num_steps_can_sample() == host._size
+        assert dev.get_diagnostics()["size"] == host._size
+    assert dev.num_steps_can_sample() == cap
+    idx = np.arange(cap, dtype=np.int64)[:992]
+    got = dev.gather(idx)
+    want = dict(observations=host._obs[idx], actions=host._act[idx], rewards=host._rew[idx],
+                terminals=host._term[idx], next_observations=host._next_obs[idx])
+    assert_batch_equal(got, want)
+
+
+def test_device_batched_gather_matches_per_call_batches():
+    host, dev = make_buffers(20_000, 20_000, 42, 7, seed=6, term_frac=0.0)
+    dev.seed(59)
+    rs = np.random.RandomState(59)
+    dev.sample_gather_device(256, 37)
+    for s in (0, 1, 17, 36):
+        pass
+    want_idx = np.stack([rs.randint(0, 20_000, 256) for _ in range(37)])
+    for s in (0, 1, 17, 36):
+        got, gidx = dev.read_slot(s, 256)
+        assert np.array_equal(gidx, want_idx[s])
+        i = want_idx[s]
+        assert_batch_equal(got, dict(observations=host._obs[i], actions=host._act[i], rewards=host._rew[i],
+                                     terminals=host._term[i], next_observations=host._next_obs[i]))

@@ -1,0 +1,143 @@
+"""GPU parity: one SAC gradient step (libsac_hip.so through the C ABI) against the CPU oracle
+(oracle/sac_step_torch.py, "rlkit-equivalent restatement") from identical state, identical
+batch and identical N(0,1) draws.
+
+Tolerance (BASELINE.json north_star): losses / logged scalars within 1e-5, read as
+|a-b| <= 1e-5 * max(1, |b|) (SURVEY.md section 7 "1e-5 on fp32 losses").  fp32 MFMA accumulates
+in a different order than the CPU GEMM, so per-element tensors are compared at 2e-5 of the
+tensor's scale."""
+import numpy as np
+import pytest
+
+from robosuite_benchmark_amd._lib import DIAG_NAMES
+from tests.helpers import TASK_DIMS, flat_of, make_pair, rel_err, synth_transitions
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def batch_and_noise(B, O, A, seed, term_frac=0.0):
+    obs, act, rew, term, nobs = synth_transitions(B, O, A, seed=seed, term_frac=term_frac)
+    rs = np.random.RandomState(seed + 1)
+    e1 = rs.normal(0, 1, (B, A)).astype(np.float32)
+    e2 = rs.normal(0, 1, (B, A)).astype(np.float32)
+    np_batch = dict(observations=obs, actions=act, rewards=rew, terminals=term.astype(np.float32),
+                    next_observations=nobs)
+    return np_batch, (e1, e2)
+
+
+def check_diag(diag, want, tol=TOL):
+    for i, name in enumerate(DIAG_NAMES):
+        assert abs(diag[i] - want[name]) <= tol * max(1.0, abs(want[name])), (name, diag[i], want[name])
+
+
+def scale_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(1e-30, np.max(np.abs(want))))
+
+
+CASES = [("Lift", 128, 0.0), ("Lift", 256, 0.0), ("Door", 1024, 0.0), ("TwoArmLift", 256, 0.0),
+         ("Lift", 256, 0.05), ("Wipe", 128, 0.0), ("Lift", 16, 0.0)]
+
+
+@pytest.mark.parametrize("task,B,term_frac", CASES)
+def test_single_step_from_identical_state(task, B, term_frac):
+    O, A = TASK_DIMS[task]
+    oracle, hip = make_pair(O, A, B, seed=11)
+    np_batch, eps = batch_and_noise(B, O, A, seed=21, term_frac=term_frac)
+    want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"], np_batch["terminals"],
+                       np_batch["next_observations"], *eps)
+    diag = hip.train(np_batch, eps=eps)
+    check_diag(diag, want)
+    L = oracle.last
+    # forward intermediates
+    for name, ref in (("a_new", L["a_new"]), ("mu", L["mu"]), ("log_std", L["log_std"]), ("a_next", L["a2"])):
+        assert scale_err(hip.debug_fetch(name, B * A), ref.detach().numpy().ravel()) < 2e-5, name
+    for name, ref in (("log_pi", L["log_pi"]), ("log_pi_next", L["log_pi2"]), ("q1", L["q1"]), ("q2", L["q2"]),
+                      ("q_target", L["y"]), ("q1_new", L["q1_new"]), ("q2_new", L["q2_new"])):
+        assert rel_err(hip.debug_fetch(name, B), ref.detach().numpy().ravel()) < 2e-5, name
+    # gradients (flat nn.Linear layout), relative to the gradient's own scale
+    for name, key in (("g_policy", "g_policy"), ("g_qf1", "g_qf1"), ("g_qf2", "g_qf2")):
+        ws, bs = L[key][:len(L[key]) // 2], L[key][len(L[key]) // 2:]
+        ref = np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(ws, bs)])
+        got = hip.debug_fetch(name, ref.size)
+        assert scale_err(got, ref) < 5e-5, name
+    # parameters after Adam + Polyak.  Adam's first step moves each weight by ~lr*sign(g): where the
+    # true gradient is ~0 the sign is numerically undetermined, so compare at a fraction of lr.
+    st = hip.state_dict()
+    after = oracle.export_nets()
+    for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+        ref = flat_of(after[name])
+        d = np.abs(st["params"][name] - ref)
+        lr = 1e-3 if name == "policy" else 5e-4
+        assert np.max(d) <= 2.0 * lr + 1e-7, name
+        assert np.mean(d > 0.02 * lr) < 2e-3, (name, float(np.mean(d > 0.02 * lr)))
+    sc = st["scalars"]
+    assert sc[3] == 1 and sc[4] == 1
+    assert abs(sc[5] - want["Alpha"]) < 1e-7
+
+
+def test_ten_steps_track_the_oracle():
+    """Both sides step their own state for 10 steps on the same batches/noise; logged scalars stay
+    within 1e-4 (trajectories diverge chaotically later -- SURVEY.md section 7)."""
+    O, A, B = 42, 7, 256
+    oracle, hip = make_pair(O, A, B, seed=5)
+    for s in range(10):
+        np_batch, eps = batch_and_noise(B, O, A, seed=100 + s)
+        want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"],
+                           np_batch["terminals"], np_batch["next_observations"], *eps)
+        diag = hip.train(np_batch, eps=eps)
+        check_diag(diag, want, tol=1e-4 if s else TOL)
+    sc = hip.state_dict()["scalars"]
+    assert sc[3] == 10 and sc[4] == 10
+
+
+def test_known_answers_on_device():
+    """KA1 (Alpha after the first step, Alpha Loss = -0.0) and KA3 (logged Policy Loss has no alpha)."""
+    O, A, B = 42, 7, 128
+    _, hip = make_pair(O, A, B, seed=2)
+    np_batch, eps = batch_and_noise(B, O, A, seed=7)
+    d = hip.train(np_batch, eps=eps)
+    assert d[DIAG_NAMES.index("Alpha")] == np.float32(np.exp(np.float32(-1e-3)))
+    assert d[DIAG_NAMES.index("Alpha Loss")] == 0.0 and np.signbit(d[DIAG_NAMES.index("Alpha Loss")])
+    lp = hip.debug_fetch("log_pi", B)
+    qn = np.minimum(hip.debug_fetch("q1_new", B), hip.debug_fetch("q2_new", B))
+    assert abs(d[DIAG_NAMES.index("Policy Loss")] - np.mean(lp - qn)) < 1e-5
+    assert d[DIAG_NAMES.index("Policy log std Max")] <= 2.0
+
+
+def test_fixed_alpha_and_reward_scale_variant():
+    O, A, B = 46, 7, 64
+    oracle, hip = make_pair(O, A, B, seed=9, use_automatic_entropy_tuning=False, reward_scale=3.0,
+                            target_update_period=1, soft_target_tau=0.01, discount=0.9)
+    for s in range(3):
+        np_batch, eps = batch_and_noise(B, O, A, seed=40 + s, term_frac=0.2)
+        want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"],
+                           np_batch["terminals"], np_batch["next_observations"], *eps)
+        diag = hip.train(np_batch, eps=eps)
+        check_diag(diag, want, tol=1e-4 if s else TOL)
+
+
+def test_device_noise_stream_is_standard_normal_and_reproducible():
+    O, A, B = 42, 7, 1024
+    _, hip = make_pair(O, A, B, seed=1, noise_seed=123)
+    _, hip2 = make_pair(O, A, B, seed=1, noise_seed=123)
+    np_batch, _ = batch_and_noise(B, O, A, seed=3)
+    d1, d2 = hip.train(np_batch), hip2.train(np_batch)
+    assert np.array_equal(d1, d2)
+    # z = mu + std*eps with mu ~ 0, std ~ 1 at init => z ~ N(0,1)
+    out = np.empty(B * A, np.float32)
+    z = hip.debug_fetch("a_new", B * A)
+    z = np.arctanh(np.clip(z, -0.999999, 0.999999))
+    assert abs(np.mean(z)) < 0.05 and abs(np.std(z) - 1.0) < 0.05
+
+
+def test_errors_are_reported_not_fatal():
+    from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy
+    pol = TanhGaussianPolicy([256, 256], 10, 3)
+    qs = [FlattenMlp([256, 256], 1, 13) for _ in range(4)]
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=100)
+    pol2 = TanhGaussianPolicy([128, 128], 10, 3)
+    with pytest.raises(RuntimeError, match="hidden_sizes"):
+        SACTrainer(policy=pol2, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=64)

@@ -1,0 +1,63 @@
+"""GPU parity: the fused hot loop (sac_train_loop = n x {random_batch; train}, all on the device)
+against the same library driven step by step through the reference-shaped interface
+(random_batch -> train), and the sampled indices against NumPy."""
+import numpy as np
+import pytest
+
+from robosuite_benchmark_amd._lib import DIAG_NAMES
+from tests.helpers import make_pair, synth_transitions
+
+pytestmark = pytest.mark.gpu
+
+
+def filled_buffer(n, O, A, seed):
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=seed)
+    buf = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
+    buf.add_block(obs, act, rew, nobs, term)
+    return buf
+
+
+@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 128, 25), (42, 7, 256, 12), (89, 14, 256, 6)])
+def test_fused_loop_equals_stepwise_interface(O, A, B, steps):
+    n = 10_000
+    _, fused = make_pair(O, A, B, seed=4, noise_seed=77)
+    _, stepw = make_pair(O, A, B, seed=4, noise_seed=77)
+    buf_a, buf_b = filled_buffer(n, O, A, 8), filled_buffer(n, O, A, 8)
+    buf_a.seed(17)
+    buf_b.seed(17)
+    first, last = fused.train_loop(buf_a, steps, batch_size=B)
+    rs = np.random.RandomState(17)
+    diags = []
+    for _ in range(steps):
+        batch, idx = buf_b.random_batch(B, return_indices=True)
+        assert np.array_equal(idx, rs.randint(0, n, B))
+        diags.append(stepw.train(batch))          # device noise stream, keyed by the step counter
+    assert np.array_equal(first, diags[0])
+    assert np.array_equal(last, diags[-1])
+    trace = fused.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
+    assert np.array_equal(trace, np.stack(diags))
+    sa, sb = fused.state_dict(), stepw.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
+    # both generators stopped at the same place in the NumPy stream
+    ka, pa = buf_a.rng_state()
+    kb, pb = buf_b.rng_state()
+    assert pa == pb and np.array_equal(ka, kb)
+
+
+def test_loop_learns_and_counters_advance():
+    O, A, B = 42, 7, 128
+    _, hip = make_pair(O, A, B, seed=6)
+    buf = filled_buffer(5000, O, A, 3)
+    buf.seed(1)
+    first, last = hip.train_loop(buf, 200, batch_size=B)
+    i = DIAG_NAMES.index
+    assert np.all(np.isfinite(first)) and np.all(np.isfinite(last))
+    assert last[i("QF1 Loss")] < first[i("QF1 Loss")]        # critics fit the bootstrapped target
+    assert last[i("Alpha")] < first[i("Alpha")]              # entropy above target => alpha decays
+    sc = hip.state_dict()["scalars"]
+    assert sc[3] == 200 and sc[4] == 200
+    t = hip.loop_timing_ms()
+    assert t["steps"] > 0 and t["gather"] > 0
