@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- SAC gradient-steps/second of the MI355X-native hot loop.
+
+A "step" = one pass of the hot path over one minibatch: random_batch index draw + row gather +
+one full SAC gradient step (rlkit_custom.py:234-238 of the reference), with the replay buffer
+already resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1: BASELINE.json configs[1] (Lift-Panda-OSC-POSE: obs 42 / act 7, batch 256, 1e6-slot buffer, full).
+N > 1: one independent replica per GPU (independent seed of the same workload; `--sweep` runs the
+8-task sweep of configs[4] instead), no data-path collective, one RCCL all-gather of the per-GPU
+results at the end ("weak" scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = 256
+SWEEP = [("Lift", 42, 7), ("Door", 46, 7), ("Stack", 55, 7), ("Wipe", 379, 6), ("PickPlaceCan", 46, 7),
+         ("NutAssemblyRound", 46, 7), ("TwoArmPegInHole", 73, 12), ("TwoArmHandoff", 86, 14)]
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def flops_per_kernel(B, O, A):
+    """Algorithmic FLOPs per launch of each step kernel (SURVEY.md section 8d formulas, split by kernel)."""
+    P = O * H + H * H + 2 * H * A              # policy MACs / sample
+    Q = (O + A) * H + H * H + H                # Q MACs / sample
+    return {
+        "k_policy_fwd": 2 * B * 2 * P,                                   # pi(s), pi(s')
+        "k_q_fwd": 2 * B * 6 * Q,                                        # six Q passes
+        "k_q_bwd": 2 * B * (2 * (H + H * H) + 2 * (H + H * H + A * H)),  # critic dX (2 nets) + actor dX (2 nets)
+        "k_policy_bwd": 2 * B * (2 * A * H + H * H),                     # head^T, fc1^T
+        "k_dw_adam": 2 * B * (2 * Q + P),                                # dW of two critics + policy
+    }
+
+
+def gather_bytes_per_step(B, O, A):
+    return 2 * B * (2 * O + A + 2) * 4 + 8 * B
+
+
+def fill_buffer(buf, n, O, A, seed):
+    rs = np.random.RandomState(seed)
+    chunk = 125_000
+    done = 0
+    while done < n:
+        m = min(chunk, n - done)
+        obs = rs.normal(0, 0.5, (m, O)).astype(np.float32)
+        nobs = rs.normal(0, 0.5, (m, O)).astype(np.float32)
+        act = rs.uniform(-1, 1, (m, A)).astype(np.float32)
+        rew = rs.uniform(0, 1, m).astype(np.float32)
+        buf.add_block(obs, act, rew, nobs, np.zeros(m, np.uint8))       # terminals always 0 (ignore_done)
+        done += m
+
+
+def build_replica(task, O, A, B, n_buf, seed, device):
+    from robosuite_benchmark_amd import EnvReplayBuffer, FlattenMlp, SACTrainer, TanhGaussianPolicy
+    rs = np.random.RandomState(seed)
+    pol = TanhGaussianPolicy([H, H], O, A, rs=rs)
+    qs = [FlattenMlp([H, H], 1, O + A, rs=rs) for _ in range(4)]
+    # trainer_kwargs of every shipped variant.json (RUN17/variant.json:52-58)
+    trainer = SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], discount=0.99,
+                         reward_scale=1.0, policy_lr=1e-3, qf_lr=5e-4, soft_target_tau=0.005,
+                         target_update_period=5, use_automatic_entropy_tuning=True, batch_size=B,
+                         noise_seed=seed, device=device)
+    buf = EnvReplayBuffer(n_buf, obs_dim=O, action_dim=A, device=device)
+    fill_buffer(buf, n_buf, O, A, 1234 + seed)
+    buf.seed(seed)
+    return trainer, buf
+
+
+def cpu_baseline(O, A, B, seconds_budget=24.0):
+    """The oracle (rlkit-equivalent torch restatement + reference-shaped float64 host buffer) timed on
+    this box's host cores: bounded sample of the same workload."""
+    import torch
+    from oracle.sac_step_torch import HostReplayBuffer, RlkitEquivalentSAC, init_sac_params, np_to_f32_batch
+    n_host = 100_000
+    rs = np.random.RandomState(0)
+    hb = HostReplayBuffer(n_host, O, A)
+    hb.fill_block(rs.normal(0, 0.5, (n_host, O)), rs.uniform(-1, 1, (n_host, A)), rs.uniform(0, 1, (n_host, 1)),
+                  np.zeros((n_host, 1), np.uint8), rs.normal(0, 0.5, (n_host, O)))
+    sac = RlkitEquivalentSAC(init_sac_params(O, A, seed=0), A, policy_lr=1e-3, qf_lr=5e-4, soft_target_tau=0.005,
+                             target_update_period=5)
+    np.random.seed(17)
+    torch.manual_seed(17)
+    default_threads = int(torch.get_num_threads())
+    share = max(1, min(16, os.cpu_count() or 1))      # a one-GPU box's CPU share is 16 cores
+
+    def one():
+        b, _ = hb.random_batch(B)
+        b = np_to_f32_batch(b)
+        e1, e2 = torch.randn(B, A).numpy(), torch.randn(B, A).numpy()
+        sac.step(b["observations"], b["actions"], b["rewards"], b["terminals"], b["next_observations"], e1, e2)
+
+    def timed(threads, budget):
+        torch.set_num_threads(threads)
+        for _ in range(10):
+            one()
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget or n >= 2000:
+                break
+        return n / el, n
+
+    # eager torch on ~60 small ops per step does not scale with threads: time 1 thread and the box's
+    # CPU share, report the faster (torch's default of one thread per host CPU is far slower).
+    r1, n1 = timed(1, seconds_budget / 2)
+    rs_, ns = timed(share, seconds_budget / 2)
+    torch.set_num_threads(default_threads)
+    best, cores, n = (r1, 1, n1) if r1 >= rs_ else (rs_, share, ns)
+    return dict(value=round(best, 2), unit="grad-steps/s", cores=cores, kind="port",
+                sample=f"{n} steps of the same workload (batch {B}, obs {O}, act {A}) after 10 warm-up; "
+                       f"reference-shaped float64 host buffer of {n_host} rows; torch {torch.__version__} CPU eager; "
+                       f"1 thread: {r1:.1f}/s, {share} threads: {rs_:.1f}/s",
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--buffer", type=int, default=1_000_000)
+    ap.add_argument("--sweep", action="store_true", help="N>1: 8-task sweep (BASELINE configs[4]) instead of seeds")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=500)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    task, O, A = SWEEP[rank % len(SWEEP)] if (args.sweep and world > 1) else SWEEP[0]
+    B = args.batch
+    trainer, buf = build_replica(task, O, A, B, args.buffer, seed=17 + rank, device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        trainer._lib.sac_sync(trainer._h)
+
+    # ---- warm-up (untimed), then EXACTLY K timed steps --------------------------------------
+    if args.warmup > 0:
+        trainer.train_loop(buf, args.warmup, batch_size=B)
+    barrier()
+    t0 = time.perf_counter()
+    first, last = trainer.train_loop(buf, args.steps, batch_size=B)      # returns after the stream drained
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = trainer.loop_timing_ms()
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed_max = float(tmax.item())
+        # the only collective of the job: per-GPU result vectors (steps/s, last losses) all-gathered
+        mine = torch.tensor([args.steps / elapsed, float(last[0]), float(last[1]), float(last[28])], device="cuda",
+                            dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_gpu = [[float(x) for x in r.tolist()] for r in allr]
+    else:
+        elapsed_max = elapsed
+        per_gpu = [[args.steps / elapsed, float(last[0]), float(last[1]), float(last[28])]]
+
+    out = None
+    if rank == 0:
+        value = world * args.steps / elapsed_max
+        # ---- per-kernel durations: instrumented replay of the same loop (HIP events on the
+        #      launching streams), N=1 / rank 0 only ------------------------------------------
+        prof = trainer.profile_loop(buf, min(args.profile_steps, args.steps, 4096), batch_size=B)
+        fl = flops_per_kernel(B, O, A)
+        kern = {}
+        for k, f in fl.items():
+            ms = prof[k]
+            kern[k] = dict(ms=round(ms, 5), gflop=round(f / 1e9, 5), tflops=round(f / (ms * 1e-3) / 1e12, 3))
+        nprof = min(args.profile_steps, args.steps, 4096)
+        gb = gather_bytes_per_step(B, O, A) * nprof
+        kern["k_gather"] = dict(ms=round(prof["k_gather"], 5), bytes=gb,
+                                gbs=round(gb / (prof["k_gather"] * 1e-3) / 1e9, 2),
+                                frac_hbm=round(gb / (prof["k_gather"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+        kern["k_mt_randint"] = dict(ms=round(prof["k_mt_randint"], 5), indices=nprof * B)
+        dom = max(fl, key=lambda k: prof[k])
+        achieved = fl[dom] / (prof[dom] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None,
+                        flops_per_launch=fl[dom], avg_launch_ms=round(prof[dom], 5),
+                        whole_step=dict(gflop=round(sum(fl.values()) / 1e9, 4),
+                                        tflops=round(sum(fl.values()) * value / world / 1e12, 3),
+                                        frac=round(sum(fl.values()) * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5)))
+        out = {
+            "metric": "SAC grad-steps/sec (batch=256, 1e6 buffer) at 1/2/4/8 GPU" if B == 256 else
+                      f"SAC grad-steps/sec (batch={B})",
+            "value": round(value, 2), "unit": "grad-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (SURVEY.md 8d: obs~N(0,.5^2), act~U(-1,1), rew~U(0,1), terminals 0; "
+                    "rlkit-style random init)",
+            "config": {"workload": f"{task}-Panda-OSC-POSE SAC inner loop: obs {O} / act {A}, batch {B}, "
+                                   f"{args.buffer}-slot HBM replay buffer (full), hidden 256x256, "
+                                   "variant.json trainer_kwargs (lr 1e-3/5e-4, tau .005, period 5)",
+                       "parallelism": ("independent task per GPU (8-task sweep)" if args.sweep and world > 1
+                                       else "independent seed per GPU, no data-path collective") if world > 1
+                       else "single GPU",
+                       "per_step": "MT19937 index draw + row gather + full SAC gradient step"},
+            "device_ms": {k: round(v, 3) for k, v in dev_ms.items()},
+            "roofline": roofline,
+            "kernels": kern,
+            "per_gpu": per_gpu,
+            "final": {"QF1 Loss": float(last[0]), "QF2 Loss": float(last[1]), "Alpha": float(last[28])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, A, B)
+        elif world == 1:
+            out["cpu_baseline"] = None
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -163,6 +163,11 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *
 int sac_sync(sac_trainer_t *t);
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms);
 
+/* profiling pass: the same loop with HIP events (on the launching streams) around every kernel.
+ * out_ms[8] = {index kernel, gather kernel, then the MEAN per-launch ms of k_policy_fwd, k_q_fwd,
+ * k_q_bwd, k_policy_bwd, k_dw_adam, and the wall ms of all n_steps steps}.  n_steps <= 4096. */
+int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float out_ms[8]);
+
 /* test access to intermediates of the last step: name in {"a_new","log_pi","mu","log_std","q1","q2",
  * "q_target","q1_new","q2_new","a_next","log_pi_next","g_policy","g_qf1","g_qf2"} (g_* = flat
  * gradient in the sac_get_params layout).  Returns the element count, <0 on error. */

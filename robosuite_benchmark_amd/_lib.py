@@ -71,6 +71,7 @@ SYMBOLS = {
     "sac_train_loop": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "sac_sync": (C.c_int, [_P]),
     "sac_last_loop_ms": (C.c_int, [_P, _F, _F, _F, _F]),
+    "sac_profile_loop": (C.c_int, [_P, _P, C.c_int64, _P]),
     "sac_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "sac_policy_mirror": (C.c_int, [_P]),
     "sac_policy_act": (C.c_int, [_P, _P, C.c_int, _P, _P]),

@@ -825,9 +825,69 @@ int launch_step(sac_trainer *t, const float *slots, const SlotLayout &SL, int n_
     return 0;
 }
 
+// same five launches with HIP events between them (profiling pass only)
+int launch_step_timed(sac_trainer *t, const float *slots, const SlotLayout &SL, int n_slots, hipEvent_t *ev) {
+    const Dev &d = t->dev;
+    hipStream_t s = t->stream;
+    const int NB = t->NB;
+    SAC_HIP(hipEventRecord(ev[0], s));
+    if (t->NH == 16) hipLaunchKernelGGL(k_policy_fwd<1>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
+    else hipLaunchKernelGGL(k_policy_fwd<2>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
+    SAC_HIP(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(k_q_fwd, dim3(6 * NB), dim3(256), t->lds_qf, s, d, slots, SL, n_slots);
+    SAC_HIP(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, slots, SL, n_slots);
+    SAC_HIP(hipEventRecord(ev[3], s));
+    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
+    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
+    SAC_HIP(hipEventRecord(ev[4], s));
+    hipLaunchKernelGGL(k_dw_adam, dim3(t->njobs + 1), dim3(256), 0, s, d, t->d_jobs, t->njobs, slots, SL, n_slots);
+    SAC_HIP(hipEventRecord(ev[5], s));
+    SAC_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[8]) {
+    SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
+    SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
+    SAC_HIP(hipSetDevice(t->device));
+    hipStream_t s = t->stream;
+    t->dev.eps1 = t->dev.eps2 = nullptr;
+    if (ensure_slots(b, t->B, n_steps)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[0], b->stream));
+    if (launch_sample(b, t->B, n_steps)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[1], b->stream));
+    if (launch_gather(b, b->d_idx, t->B, n_steps, b->d_slots, b->slot, 1)) return -1;
+    SAC_HIP(hipEventRecord(b->ev[2], b->stream));
+    SAC_HIP(hipStreamWaitEvent(s, b->ev[2], 0));
+    int zero = 0;
+    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_pos, &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    std::vector<hipEvent_t> ev((size_t)n_steps * 6);
+    for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
+    for (int64_t i = 0; i < n_steps; ++i)
+        if (launch_step_timed(t, b->d_slots, b->slot, (int)n_steps, &ev[(size_t)i * 6])) return -1;
+    SAC_HIP(hipStreamSynchronize(s));
+    double acc[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n_steps; ++i)
+        for (int k = 0; k < 5; ++k) {
+            float ms = 0.f;
+            SAC_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 6 + k], ev[(size_t)i * 6 + k + 1]));
+            acc[k] += ms;
+        }
+    float tot = 0.f;
+    SAC_HIP(hipEventElapsedTime(&tot, ev[0], ev[(size_t)n_steps * 6 - 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    SAC_HIP(hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
+    SAC_HIP(hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
+    for (int k = 0; k < 5; ++k) out_ms[2 + k] = (float)(acc[k] / (double)n_steps);
+    out_ms[7] = tot;
+    t->mirror_valid = false;
+    return 0;
+}
 
 int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     SAC_REQUIRE(out && cfg, "null argument to sac_trainer_create");

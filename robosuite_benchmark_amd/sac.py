@@ -141,6 +141,20 @@ class SACTrainer:
         self._record(first)
         return first, last
 
+    def profile_loop(self, replay_buffer, n_steps, batch_size=None):
+        """Instrumented pass: per-kernel mean launch duration (ms) from HIP events."""
+        B = int(batch_size or self._batch)
+        if self._h is None or B != self._batch:
+            self._create(B)
+        ms = np.zeros(8, np.float32)
+        _lib.check(self._lib.sac_profile_loop(self._h, replay_buffer._h, int(n_steps), _lib.ptr(ms)),
+                   "sac_profile_loop")
+        self._num_train_steps += int(n_steps)
+        self._host_policy_stale = True
+        names = ["k_mt_randint", "k_gather", "k_policy_fwd", "k_q_fwd", "k_q_bwd", "k_policy_bwd", "k_dw_adam",
+                 "steps_wall"]
+        return OrderedDict(zip(names, [float(x) for x in ms]))
+
     def loop_timing_ms(self):
         v = [C.c_float() for _ in range(4)]
         _lib.check(self._lib.sac_last_loop_ms(self._h, *[C.byref(x) for x in v]), "sac_last_loop_ms")
