@@ -12,10 +12,16 @@
 // the Polyak update in its epilogue, so gradients never round-trip through HBM.
 //
 //   K1 k_policy_fwd   2*B/16 WGs   pi(s), pi(s') : 3 layers + tanh-Gaussian head, log_pi
-//   K2 k_q_fwd        6*B/16 WGs   Q1,Q2 on (s,a), (s,a_new); T1,T2 on (s',a')  (+ alpha Adam step)
+//   K2 k_q_fwd        6*B/16+1     Q1,Q2 on (s,a), (s,a_new); T1,T2 on (s',a')  (+ alpha Adam step)
 //   K3 k_q_bwd        4*B/16 WGs   critic dL/dh (2 nets), actor dQ/da (2 nets)
 //   K4 k_policy_bwd     B/16 WGs   head gradient (reparameterised), dL/dh
 //   K5 k_dw_adam      ~250  WGs    dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
+//
+// Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round
+// trips, not by FLOPs): the minibatch slot and the step index are launch arguments (no dependent
+// load in front of the first data access); everything a kernel will need later -- ReLU masks,
+// the first D k-chunks of the NEXT layer's weights, device-side scalars -- is loaded at kernel
+// entry into registers, so one L2/Infinity-Cache round trip is paid per kernel, not per layer.
 #include "sac_common.h"
 
 #include <cmath>
@@ -30,24 +36,30 @@ constexpr int H = 256;            // hidden width (every shipped variant.json)
 constexpr float LOG_SIG_MAX = 2.0f, LOG_SIG_MIN = -20.0f, TANH_EPS = 1e-6f;
 constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 constexpr int DIAG_TRACE_CAP = 4096;
+constexpr int RD = 4;             // ring depth (k-chunks in flight) for the runtime-K first layers
+#ifndef SAC_RDH
+#define SAC_RDH 4
+#endif
+constexpr int RDH4 = SAC_RDH;     // hidden layers' ring depth (measured: 4 > 16; the weight stream is bound by the
+                                  // per-CU fill rate from the Infinity Cache, not by exposed latency)
 
-struct Ctl {                       // device-resident step state (read by every kernel at entry)
-    long long n_train_steps_total; // rlkit _n_train_steps_total
-    long long adam_t;              // optimizer step count (all four optimizers step together)
-    int loop_pos;                  // step index inside the current sac_train_loop / 0 for sac_step
-    unsigned ticket;               // K5 arrival counter
+struct Ctl {                       // device-resident step state
+    long long step_base;           // rlkit _n_train_steps_total at the start of the current chunk
+    long long adam_base;           // optimizer step count at the start of the current chunk
+    int loop_base;                 // steps of the current sac_train_loop already finished
     float log_alpha, a_m, a_v, alpha, alpha_loss;
-    int pad[3];
+    int pad[2];
+    double bc1, bc2s;              // 1 - beta1^t, sqrt(1 - beta2^t) of the CURRENT step (K2 writes)
 };
 
 struct Layer {                     // one nn.Linear in the padded device layout
     int N, K, Np, Kp;
     long long offW, offB;          // in P / M / V / G : W [Np][Kp], b [Np]
-    long long offWt;               // in PT : W^T [Kp + 16][Np]
+    long long offWt;               // in PT / MT / VT : W^T [Kp + 16][Np]
 };
 
 struct Net {
-    float *P = nullptr, *M = nullptr, *V = nullptr, *PT = nullptr, *G = nullptr;
+    float *P = nullptr, *M = nullptr, *V = nullptr, *PT = nullptr, *MT = nullptr, *VT = nullptr, *G = nullptr;
     long long nP = 0, nPT = 0;
     Layer L[3];
 };
@@ -75,16 +87,36 @@ struct Dev {
     const float *eps1, *eps2;
 };
 
-struct DwJob {
-    const float *dYT, *XT;         // rows n0.. of dY^T [.][B]; rows k0.. of X^T [.][B]
-    float *P, *M, *V, *PT, *G;     // layer bases (W part)
-    float *bias, *mb, *vb, *gb;    // non-null only for the k0 == 0 strip
-    float *TP, *Tbias;             // Polyak target (W base / bias), or null
-    int N, K, n0, k0, ldp, ldt;
-    float lr;
-    int xt_from_slot;              // XT is an offset into the current minibatch slot (saT)
+// weight-gradient work table (kernel argument of K5): one entry per trained layer
+struct DwLayer {
+    const float *dYT, *XT;         // dY^T [Np][B]; X^T [>= 64*nk rows][B] (or offset into the slot)
     long long xt_off;
+    float *P, *PT, *MT, *VT, *G;   // forward copy [Np][Kp], transposed copy + Adam moments [Kp+16][Np]
+    float *bias, *mb, *vb, *gb;    // bias, its moments, its gradient (debug)
+    float *TP, *Tbias;             // Polyak target (forward copy / bias) or null
+    int N, K, ldp, ldt, nk, job0, xt_from_slot;
+    float lr;
 };
+constexpr int NDW = 9;
+struct DwTable { DwLayer L[NDW]; int njobs; };
+
+// ------------------------------------------------------------------------------------------
+// in-kernel stamps (diagnostic build only, -DSAC_STAMPS; the shipped library has none)
+// ------------------------------------------------------------------------------------------
+#ifdef SAC_STAMPS
+__device__ unsigned long long g_stamps[5 * 512 * 16];
+#define STAMP(kid, i)                                                                              \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (threadIdx.x == 0 && blockIdx.x < 512) {                                                \
+            g_stamps[((kid) * 512 + blockIdx.x) * 16 + (i)] = wall_clock64();                      \
+            g_stamps[((kid) * 512 + blockIdx.x) * 16 + 8 + (i)] = clock64();                       \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#else
+#define STAMP(kid, i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -92,49 +124,102 @@ struct DwJob {
 __device__ __forceinline__ int lds_off(int row, int k, int KL) {
     return row * KL + ((((k >> 2) ^ (row & 15)) << 2) | (k & 3));
 }
+// hipcc sinks prefetch loads down to their first use (and hoists bulk loads above small critical
+// ones); vmcnt completes in issue order, so the ISSUE ORDER is part of the design.  SB pins it.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
-// acc[t] += X[16 x 16*KS] * W[cols n_base + t*n_stride .. +16][.]^T  for this wave's NT column tiles.
-// X: LDS row-block, row stride KL (multiple of 64), 16-B chunks XOR-swizzled by row.
-// W: global [n][ldw] (ldw multiple of 4).  Contraction index order is permuted (lane group g owns
-// k = 16S + 4g + i), identically for both operands.
-template <int NT>
-__device__ __forceinline__ void gemm_tiles(const float *X, int KL, int S0, int S1, const float *__restrict__ W,
-                                           int ldw, int n_base, int n_stride, f32x4 (&acc)[NT]) {
+// Weight stream of one wave: NT column tiles of 16 outputs, k-chunks of 16 held in a D-deep
+// register ring.  W is [n][ldw] (ldw % 4 == 0); lane (c = lane&15, g = lane>>4) loads the 16 B
+// W[n0_t + c][16 S + 4 g .. +3], i.e. lane group g owns contraction index k = 16S + 4g + i.
+#ifndef SAC_ROT
+#define SAC_ROT(b) (((b) >> 3) * 4)
+#endif
+#ifdef SAC_EXPERIMENT_CONTIG
+#define CHUNK_STRIDE 256
+#else
+#define CHUNK_STRIDE 16
+#endif
+template <int NT, int D = RD>
+struct WRing {
+    f32x4 b[D][NT];
+    const float *wp[NT];
+    int rot = 0, rmask = 0;          // chunk S is fetched as (S + rot) & rmask when rmask != 0
+    // Workgroups that share a weight matrix on one XCD start their sweep at different k-chunks: each
+    // line is then missed (Infinity-Cache latency) by one of them and L2-hit by the others, instead of
+    // every workgroup waiting on the same in-flight fills.  Any order of the contraction is valid.
+    __device__ __forceinline__ void rotate(int r, int KS) { rot = r & (KS - 1); rmask = KS - 1; }
+    __device__ __forceinline__ int chunk(int S) const { return rmask ? ((S + rot) & rmask) : S; }
+    __device__ __forceinline__ void init(const float *W, int ldw, int n_base, int n_stride, int s_off = 0) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#ifdef SAC_EXPERIMENT_CONTIG
+            wp[t] = (ldw == H) ? W + ((size_t)((n_base >> 4) + t) * (H / 16) * 64 + lane) * 4 - (size_t)16 * 0
+                               : W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
+#else
+            wp[t] = W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
+#endif
+    }
+    __device__ __forceinline__ void fill(int KS) {        // chunks 0 .. min(D, KS)-1 into flight
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (u < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + CHUNK_STRIDE * chunk(u));
+            }
+    }
+};
+
+// acc[t] += X[16 x 16*KS] * W_t^T.  X: LDS row-block, row stride KL (multiple of 64), 16-B chunks
+// XOR-swizzled by row (conflict-free ds_read_b128 for the MFMA A operand).  The ring must have been
+// fill()ed; chunk S+RD is requested as soon as chunk S has been copied out.
+template <int NT, int D>
+__device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
+                                          int s_off = 0) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
-    const float *wp[NT];
+    f32x4 a_cur = ld4(xrow + 4 * ((4 * (R.chunk(0) + s_off) + g) ^ r));
+    for (int S0 = 0; S0 < KS; S0 += D) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wp[t] = W + (size_t)(n_base + t * n_stride + r) * ldw + 4 * g;
-#pragma unroll 2
-    for (int S = S0; S < S1; ++S) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(xrow + 4 * ((4 * S + g) ^ r));
-        f32x4 b[NT];
+        for (int u = 0; u < D; ++u) {
+            const int S = S0 + u;
+            if (S < KS) {
+                // next chunk's A fragment (LDS) and the refill of this ring slot (global) are issued
+                // BEFORE this chunk's 4*NT MFMAs and may not sink below them
+                const int Sn = (S + 1 < KS) ? S + 1 : S;
+                const f32x4 a_nxt = ld4(xrow + 4 * ((4 * (R.chunk(Sn) + s_off) + g) ^ r));
+                f32x4 bc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = *reinterpret_cast<const f32x4 *>(wp[t] + 16 * S);
+                for (int t = 0; t < NT; ++t) bc[t] = R.b[u][t];
+                if (S + D < KS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + CHUNK_STRIDE * R.chunk(S + D));
+                }
+                SB();
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], bc[t][i], acc[t], 0, 0, 0);
+                }
+                SB();
+                a_cur = a_nxt;
+            }
         }
     }
 }
 
-// one [16 x 16*NTT] output with the contraction split over the 4 waves; result (summed) lands in
-// LDS `out` as row-major [16][ldo] (+ bias).  `red` = 4*NTT*256 floats of scratch.
+// split-K epilogue: the four waves each hold a partial [16 x 16*NTT]; sum them through LDS into
+// `out` (row-major [16][ldo]) + bias.  red = 4*NTT*256 floats.
 template <int NTT>
-__device__ __forceinline__ void gemm_splitk(const float *X, int KL, int KS, const float *__restrict__ W, int ldw,
-                                            const float *__restrict__ bias, float *red, float *out, int ldo) {
+__device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const float *__restrict__ bias, float *red,
+                                              float *out, int ldo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    f32x4 acc[NTT];
 #pragma unroll
-    for (int t = 0; t < NTT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int per = (KS + 3) >> 2;
-    const int s0 = wave * per, s1 = (s0 + per < KS) ? s0 + per : KS;
-    if (s0 < s1) gemm_tiles<NTT>(X, KL, s0, s1, W, ldw, 0, 16, acc);
-#pragma unroll
-    for (int t = 0; t < NTT; ++t)
-        *reinterpret_cast<f32x4 *>(red + ((wave * NTT + t) * 64 + lane) * 4) = acc[t];
+    for (int t = 0; t < NTT; ++t) st4(red + ((wave * NTT + t) * 64 + lane) * 4, acc[t]);
     __syncthreads();
     for (int e = threadIdx.x; e < NTT * 256; e += 256) {
         const int t = e >> 8, l = (e >> 2) & 63, i = e & 3;
@@ -174,36 +259,54 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
-// fill a swizzled LDS row-block [16][KL] from row-major global rows (two sources concatenated)
-__device__ __forceinline__ void load_rows_cat(float *X, int KL, int Kfill, const float *__restrict__ s0, int n0,
-                                              int ld0, const float *__restrict__ s1, int n1, int ld1) {
-    for (int e = threadIdx.x; e < RB * Kfill; e += 256) {
-        const int row = e / Kfill, k = e - row * Kfill;
-        float v = 0.f;
-        if (k < n0) v = s0[row * ld0 + k];
-        else if (k < n0 + n1) v = s1[row * ld1 + (k - n0)];
-        X[lds_off(row, k, KL)] = v;
+// swizzled LDS row-block [16][KL] from row-major global rows (two sources concatenated), in two
+// phases: issue() puts the loads in flight early, commit() writes LDS once they are needed.
+constexpr int ROWS_MAXE = 32;                 // Kfill <= 512
+struct RowRegs {
+    float v[ROWS_MAXE];
+    __device__ __forceinline__ void issue(int Kfill, const float *__restrict__ s0, int n0, int ld0,
+                                          const float *__restrict__ s1, int n1, int ld1) {
+        const int nper = Kfill >> 4;          // RB * Kfill / 256
+#pragma unroll
+        for (int i = 0; i < ROWS_MAXE; ++i) {
+            v[i] = 0.f;
+            if (i < nper) {
+                const int e = threadIdx.x + 256 * i;
+                const int row = e / Kfill, k = e - row * Kfill;
+                if (k < n0) v[i] = s0[row * ld0 + k];
+                else if (k < n0 + n1) v[i] = s1[row * ld1 + (k - n0)];
+            }
+        }
     }
-}
+    __device__ __forceinline__ void commit(float *X, int KL, int Kfill) const {
+        const int nper = Kfill >> 4;
+#pragma unroll
+        for (int i = 0; i < ROWS_MAXE; ++i)
+            if (i < nper) {
+                const int e = threadIdx.x + 256 * i;
+                const int row = e / Kfill, k = e - row * Kfill;
+                X[lds_off(row, k, KL)] = v[i];
+            }
+    }
+};
 
 // epilogue of a hidden layer: bias + relu from the accumulators into the next LDS row-block, and
 // (optionally) the feature-major copy [n][B] for the weight-gradient kernel.
 template <int NT>
 __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_base, int n_stride,
-                                                const float *__restrict__ bias, float *Xn, int KL, float *outT,
-                                                int B, int row0) {
+                                                const float (&bv)[NT], float *Xn, int KL, float *outT, int B,
+                                                int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n_base + t * n_stride + c;
-        const float bv = bias[n];
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = fmaxf(acc[t][i] + bv, 0.f);
+            v[i] = fmaxf(acc[t][i] + bv[t], 0.f);
             Xn[lds_off(4 * g + i, n, KL)] = v[i];
         }
-        if (outT) *reinterpret_cast<f32x4 *>(outT + (size_t)n * B + row0 + 4 * g) = v;
+        if (outT) st4(outT + (size_t)n * B + row0 + 4 * g, v);
     }
 }
 
@@ -211,40 +314,61 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 // K1: policy forward on s (blocks [0,NB)) and s' (blocks [NB,2NB))
 // ------------------------------------------------------------------------------------------
 template <int NTH>
-__global__ __launch_bounds__(256) void k_policy_fwd(Dev d, const float *__restrict__ slots, SlotLayout SL,
-                                                    int n_slots) {
+__global__ __launch_bounds__(256) void k_policy_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A;
     const int KL0 = (d.KP + 63) & ~63;
     float *X0 = lds;                     // [16][KL0]
     float *X1 = X0 + RB * KL0;           // [16][256]
     float *X2 = X1 + RB * H;             // [16][256]
-    float *HD = X2 + RB * H;             // [16][NH]
+    float *HD = X2 + RB * H;             // [16][32]
     float *red = HD + RB * 32;           // split-K scratch 4*NTH*256
-    const Ctl ctl = *d.ctl;
-    const float *S = slots + (size_t)(ctl.loop_pos % n_slots) * SL.slot_floats;
     const bool next = blockIdx.x >= (unsigned)d.NB;
     const int rb = next ? blockIdx.x - d.NB : blockIdx.x;
     const int row0 = rb * RB;
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const float *P = d.P[0];
+    const long long step_base = d.ctl->step_base;          // used only by the noise counter, much later
 
-    load_rows_cat(X0, KL0, d.KP, S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
+    // ---- everything this block will need from memory, requested up front, in consumption order ----
+    WRing<4> r0;
+    WRing<4, RDH4> r1;
+    WRing<NTH> rh;
+    RowRegs rows;
+    rows.issue(d.KP, S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
+    r0.init(P + d.LP[0].offW, d.LP[0].Kp, 64 * wave, 16);
+    r0.fill(d.KP >> 4);
+    float bv0[4], bv1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv0[t] = P[d.LP[0].offB + 64 * wave + 16 * t + c];
+    SB();
+    r1.init(P + d.LP[1].offW, H, 64 * wave, 16);
+    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    r1.fill(H >> 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv1[t] = P[d.LP[1].offB + 64 * wave + 16 * t + c];
+    rh.init(P + d.LP[2].offW, H, 0, 16, 4 * wave);        // head: contraction split over the waves
+    SB();
+    rows.commit(X0, KL0, d.KP);
     __syncthreads();
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X0, KL0, 0, d.KP >> 4, P + d.LP[0].offW, d.LP[0].Kp, 64 * wave, 16, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, P + d.LP[0].offB, X1, H, next ? nullptr : d.PH1T, B, row0);
+        gemm_ring(r0, X0, KL0, d.KP >> 4, acc);
+        rh.fill(4);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, next ? nullptr : d.PH1T, B, row0);
     }
     __syncthreads();
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X1, H, 0, H >> 4, P + d.LP[1].offW, H, 64 * wave, 16, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, P + d.LP[1].offB, X2, H, next ? nullptr : d.PH2T, B, row0);
+        gemm_ring(r1, X1, H, H >> 4, acc);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, next ? nullptr : d.PH2T, B, row0);
     }
     __syncthreads();
-    gemm_splitk<NTH>(X2, H, H >> 4, P + d.LP[2].offW, H, P + d.LP[2].offB, red, HD, 32);
-
+    {
+        f32x4 acc[NTH] = {};
+        gemm_ring(rh, X2, H, 4, acc, 4 * wave);
+        splitk_reduce<NTH>(acc, P + d.LP[2].offB, red, HD, 32);
+    }
     // tanh-Gaussian head: thread = (row, a)
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int grow = row0 + row;
@@ -256,7 +380,7 @@ __global__ __launch_bounds__(256) void k_policy_fwd(Dev d, const float *__restri
         const float stdv = expf(lstd);
         const float *epp = next ? d.eps2 : d.eps1;
         const float eps = epp ? epp[grow * A + a]
-                              : philox_normal(d.noise_seed, (unsigned long long)ctl.n_train_steps_total,
+                              : philox_normal(d.noise_seed, (unsigned long long)(step_base + j),
                                               (unsigned)(grow * 16 + a), next ? 1u : 0u);
         const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
         const float act = tanhf(zz);
@@ -297,118 +421,168 @@ __global__ __launch_bounds__(256) void k_policy_fwd(Dev d, const float *__restri
 // ------------------------------------------------------------------------------------------
 // K2: six Q forward passes.  pass = blockIdx / NB:
 //   0 Q1(s,a) 1 Q2(s,a) 2 Q1(s,a_new) 3 Q2(s,a_new) 4 T1(s',a') 5 T2(s',a')
-// Block 0 also performs the alpha Adam step (SURVEY Appendix A lines 4-6).
+// The extra last block performs the alpha Adam step (SURVEY Appendix A lines 4-6) and publishes
+// this step's Adam bias corrections for K5.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q_fwd(Dev d, const float *__restrict__ slots, SlotLayout SL, int n_slots) {
+__global__ __launch_bounds__(256) void k_q_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A;
+    if (blockIdx.x == (unsigned)(6 * d.NB)) {
+        if (threadIdx.x == 0) {
+            Ctl *c = d.ctl;
+            const double tt = (double)(c->adam_base + j + 1);
+            const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
+            c->bc1 = bc1;
+            c->bc2s = sqrt(bc2);
+            if (d.auto_alpha) {
+                float s = 0.f;
+                for (int i = 0; i < d.NB; ++i) s += d.part_logpi[i];
+                const float mean_lp = s / (float)B + d.target_entropy;      // mean(log_pi + H)
+                const float la = c->log_alpha;
+                // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0, so log_alpha == 0 logs -0.0
+                c->alpha_loss = -((la * mean_lp) + 0.0f);
+                const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
+                const float m = c->a_m + (1.0f - ADAM_B1) * (gr - c->a_m);
+                const float v = c->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
+                const float step_size = (float)((double)d.alpha_lr / bc1);
+                const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
+                const float nla = la + (-step_size * m) / denom;
+                c->a_m = m; c->a_v = v; c->log_alpha = nla;
+                c->alpha = expf(nla);
+            } else {
+                c->alpha = 1.0f;
+                c->alpha_loss = 0.0f;
+            }
+        }
+        return;
+    }
     const int KL0 = (d.KQ + 63) & ~63;
     float *X0 = lds;
     float *X1 = X0 + RB * KL0;
     float *X2 = X1 + RB * H;
-    const Ctl ctl = *d.ctl;
-    const float *S = slots + (size_t)(ctl.loop_pos % n_slots) * SL.slot_floats;
     const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
     const int row0 = rb * RB;
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const int net = (pass < 4) ? 1 + (pass & 1) : 3 + (pass & 1);
     const float *P = d.P[net];
 
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Ctl *c = d.ctl;
-        if (d.auto_alpha) {
-            float s = 0.f;
-            for (int i = 0; i < d.NB; ++i) s += d.part_logpi[i];
-            const float mean_lp = s / (float)B + d.target_entropy;      // mean(log_pi + H)
-            const float la = c->log_alpha;
-            // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0, so log_alpha == 0 logs -0.0
-            c->alpha_loss = -((la * mean_lp) + 0.0f);
-            const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
-            const double t = (double)(ctl.adam_t + 1);
-            const float m = c->a_m + (1.0f - ADAM_B1) * (gr - c->a_m);
-            const float v = c->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
-            const double bc1 = 1.0 - pow((double)ADAM_B1, t), bc2 = 1.0 - pow((double)ADAM_B2, t);
-            const float step_size = (float)((double)d.alpha_lr / bc1);
-            const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
-            const float nla = la + (-step_size * m) / denom;
-            c->a_m = m; c->a_v = v; c->log_alpha = nla;
-            c->alpha = expf(nla);
-        } else {
-            c->alpha = 1.0f;
-            c->alpha_loss = 0.0f;
-        }
-    }
-
+    WRing<4> r0;
+    WRing<4, RDH4> r1;
+    RowRegs rows;
     const float *obs = S + ((pass >= 4) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
     const float *act;
     int lda;
     if (pass < 2) { act = S + SL.off_act + (size_t)row0 * A; lda = A; }
     else if (pass < 4) { act = d.anew + (size_t)row0 * 16; lda = 16; }
     else { act = d.a2 + (size_t)row0 * 16; lda = 16; }
-    load_rows_cat(X0, KL0, d.KQ, obs, O, O, act, A, lda);
+    rows.issue(d.KQ, obs, O, O, act, A, lda);
+    r0.init(P + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
+    r0.fill(d.KQ >> 4);
+    float bv0[4], bv1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv0[t] = P[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    SB();
+    r1.init(P + d.LQ[1].offW, H, 64 * wave, 16);
+    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    r1.fill(H >> 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv1[t] = P[d.LQ[1].offB + 64 * wave + 16 * t + c];
+    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+    float w3[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w3[u] = P[d.LQ[2].offW + part + 16 * u];
+    const float b3 = P[d.LQ[2].offB];
+    SB();
+    rows.commit(X0, KL0, d.KQ);
     __syncthreads();
     float *h1T = (pass < 4) ? d.QH1T + (size_t)pass * H * B : nullptr;
     float *h2T = (pass < 4) ? d.QH2T + (size_t)pass * H * B : nullptr;
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X0, KL0, 0, d.KQ >> 4, P + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, P + d.LQ[0].offB, X1, H, h1T, B, row0);
+        gemm_ring(r0, X0, KL0, d.KQ >> 4, acc);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, h1T, B, row0);
     }
     __syncthreads();
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X1, H, 0, H >> 4, P + d.LQ[1].offW, H, 64 * wave, 16, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, P + d.LQ[1].offB, X2, H, h2T, B, row0);
+        gemm_ring(r1, X1, H, H >> 4, acc);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, h2T, B, row0);
     }
     __syncthreads();
     // last_fc: q[row] = h2[row] . w3 + b3   (N = 1: VALU dot, 16 lanes per row)
-    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
-    const float *w3 = P + d.LQ[2].offW;
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int k = part + 16 * j;
-        s += X2[lds_off(row, k, H)] * w3[k];
-    }
+    for (int u = 0; u < 16; ++u) s += X2[lds_off(row, part + 16 * u, H)] * w3[u];
     s = group16_sum(s);
-    if (part == 0) d.q[(size_t)pass * B + row0 + row] = s + P[d.LQ[2].offB];
+    if (part == 0) d.q[(size_t)pass * B + row0 + row] = s + b3;
 }
 
 // ------------------------------------------------------------------------------------------
 // K3: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through
 // Q1/Q2 down to d/da_new (input gradient only).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ slots, SlotLayout SL, int n_slots) {
+__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B;
     float *X2 = lds;                 // dL/dh2 row-block [16][256]
     float *X1 = X2 + RB * H;         // dL/dh1 row-block (actor)
     float *red = X1 + RB * H;        // 1024 floats
     __shared__ float s_dq[RB];
-    const Ctl ctl = *d.ctl;
-    const float *S = slots + (size_t)(ctl.loop_pos % n_slots) * SL.slot_floats;
     const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
     const int row0 = rb * RB;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const bool critic = pass < 2;
     const int qi = pass & 1;               // which twin
     const float *P = d.P[1 + qi];
     const float *PT = d.PT[1 + qi];
     const float invB = 1.0f / (float)B;
+    const float *h2T = d.QH2T + (size_t)pass * H * B;
+    const float *h1T = d.QH1T + (size_t)pass * H * B;
 
+    // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
+    const float alpha = d.ctl->alpha;
+    float in_a = 0.f, in_b = 0.f, in_c = 0.f, in_r = 0.f, in_t = 0.f;
+    if (threadIdx.x < RB) {
+        const int r = row0 + threadIdx.x;
+        if (critic) {
+            in_a = d.q[4 * (size_t)B + r]; in_b = d.q[5 * (size_t)B + r]; in_c = d.logpi2[r];
+            in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
+            in_a = fminf(in_a, in_b);
+            in_b = d.q[(size_t)qi * B + r];
+        } else {
+            in_a = d.q[(size_t)(2 + qi) * B + r]; in_b = d.q[(size_t)(3 - qi) * B + r];
+        }
+    }
+    const int k = threadIdx.x;
+    const float wk = P[d.LQ[2].offW + k];
+    f32x4 h2v[4], h1v[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
+    SB();
+    WRing<4, RDH4> r1;
+    r1.init(PT + d.LQ[1].offWt, H, 64 * wave, 16);
+    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    r1.fill(H >> 4);
+    SB();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1v[t] = ld4(h1T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
+    WRing<1> ra;
+    if (!critic) {
+        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * wave);
+        ra.fill(4);
+    }
+    SB();
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
         float dq;
         if (critic) {
-            const float tmin = fminf(d.q[4 * (size_t)B + r], d.q[5 * (size_t)B + r]);
-            const float tq = tmin - ctl.alpha * d.logpi2[r];
-            const float yv = d.reward_scale * S[SL.off_rew + r] + (1.0f - S[SL.off_term + r]) * d.discount * tq;
+            const float tq = in_a - alpha * in_c;
+            const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
             if (qi == 0) d.y[r] = yv;
-            dq = 2.0f * (d.q[(size_t)qi * B + r] - yv) * invB;
+            dq = 2.0f * (in_b - yv) * invB;
             d.dq16T[(size_t)qi * 16 * B + r] = dq;                  // row 0 of the padded [16][B]
         } else {
-            const float mine = d.q[(size_t)(2 + qi) * B + r], other = d.q[(size_t)(3 - qi) * B + r];
-            const float sel = (mine < other) ? 1.0f : ((mine == other) ? 0.5f : 0.0f);   // torch.min backward
+            const float sel = (in_a < in_b) ? 1.0f : ((in_a == in_b) ? 0.5f : 0.0f);   // torch.min backward
             dq = -invB * sel;
         }
         s_dq[threadIdx.x] = dq;
@@ -416,48 +590,44 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     __syncthreads();
     // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups)
     {
-        const float *h2T = d.QH2T + (size_t)pass * H * B;
-        const float *w3 = P + d.LQ[2].offW;
         float *outT = critic ? d.dQH2T + (size_t)qi * H * B : nullptr;
-        const int k = threadIdx.x;
-        const float wk = w3[k];
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(h2T + (size_t)k * B + row0 + 4 * qd);
             f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gv[i] = (hv[i] > 0.f) ? s_dq[4 * qd + i] * wk : 0.f;
+                gv[i] = (h2v[qd][i] > 0.f) ? s_dq[4 * qd + i] * wk : 0.f;
                 X2[lds_off(4 * qd + i, k, H)] = gv[i];
             }
-            if (outT) *reinterpret_cast<f32x4 *>(outT + (size_t)k * B + row0 + 4 * qd) = gv;
+            if (outT) st4(outT + (size_t)k * B + row0 + 4 * qd, gv);
         }
     }
     __syncthreads();
     // dL/dh1 = (dL/dh2 . W2) * relu'(h1)
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X2, H, 0, H >> 4, PT + d.LQ[1].offWt, H, 64 * wave, 16, acc);
-        const float *h1T = d.QH1T + (size_t)pass * H * B;
+        gemm_ring(r1, X2, H, H >> 4, acc);
         float *outT = critic ? d.dQH1T + (size_t)qi * H * B : nullptr;
-        const int c = lane & 15, g = lane >> 4;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = 64 * wave + 16 * t + c;
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(h1T + (size_t)n * B + row0 + 4 * g);
             f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gv[i] = (hv[i] > 0.f) ? acc[t][i] : 0.f;
+                gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
                 if (!critic) X1[lds_off(4 * g + i, n, H)] = gv[i];
             }
-            if (outT) *reinterpret_cast<f32x4 *>(outT + (size_t)n * B + row0 + 4 * g) = gv;
+            if (outT) st4(outT + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
     if (critic) return;
     __syncthreads();
     // d/da_new = dL/dh1 . W1[:, O:O+A]   -> da[qi][row][16]
-    gemm_splitk<1>(X1, H, H >> 4, PT + d.LQ[0].offWt + (size_t)d.O * H, H, nullptr, red, X2, 16);
+    {
+        f32x4 acc[1] = {};
+        gemm_ring(ra, X1, H, 4, acc, 4 * wave);
+        splitk_reduce<1>(acc, nullptr, red, X2, 16);
+    }
     d.da[(size_t)qi * B * 16 + (size_t)row0 * 16 + threadIdx.x] = X2[threadIdx.x];
 }
 
@@ -473,71 +643,98 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
     const int B = d.B, A = d.A;
     float *XH = lds;                 // [16][64] head gradient row-block
     float *X2 = XH + RB * 64;        // [16][256]
-    const Ctl ctl = *d.ctl;
     const int rb = blockIdx.x, row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
     const float *PT = d.PT[0];
     const float invB = 1.0f / (float)B;
 
+    STAMP(3, 0);
+    // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
+    const float alpha = d.ctl->alpha;
+    const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
+    const int gi = (row0 + row) * 16 + a;
+    float act = 0.f, dav = 0.f, lsv = 0.f, epv = 0.f, okv = 0.f;
+    if (a < A) {
+        act = d.anew[gi];
+        dav = d.da[gi] + d.da[(size_t)B * 16 + gi];
+        lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
+    }
+    SB();
+    WRing<4> rh;
+    WRing<4, RDH4> r1;
+    rh.init(PT + d.LP[2].offWt, d.LP[2].Np, 64 * wave, 16);
+    rh.fill(NTH);
+    f32x4 h2v[4], h1v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
+    SB();
+    r1.init(PT + d.LP[1].offWt, H, 64 * wave, 16);
+    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    r1.fill(H >> 4);
+    SB();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1v[t] = ld4(d.PH1T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
+    SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
     __syncthreads();
-    {
-        const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
-        const int gi = (row0 + row) * 16 + a;
-        if (a < A) {
-            const float act = d.anew[gi];
-            const float om = 1.0f - act * act;
-            const float dav = d.da[gi] + d.da[(size_t)B * 16 + gi];
-            const float dz = dav * om + (ctl.alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
-            const float stdv = expf(d.ls[gi]);
-            const float dls = (dz * stdv * d.epsv[gi] - ctl.alpha * invB) * d.lsok[gi];
-            XH[lds_off(row, a, 64)] = dz;
-            XH[lds_off(row, A + a, 64)] = dls;
-            d.dheadT[(size_t)a * B + row0 + row] = dz;
-            d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
-        }
+    STAMP(3, 1);
+    if (a < A) {
+        const float om = 1.0f - act * act;
+        const float dz = dav * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+        const float stdv = expf(lsv);
+        const float dls = (dz * stdv * epv - alpha * invB) * okv;
+        XH[lds_off(row, a, 64)] = dz;
+        XH[lds_off(row, A + a, 64)] = dls;
+        d.dheadT[(size_t)a * B + row0 + row] = dz;
+        d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
     }
     __syncthreads();
-    const int c = lane & 15, g = lane >> 4;
+    STAMP(3, 2);
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(XH, 64, 0, NTH, PT + d.LP[2].offWt, d.LP[2].Np, 64 * wave, 16, acc);
+        gemm_ring(rh, XH, 64, NTH, acc);
+        STAMP(3, 3);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = 64 * wave + 16 * t + c;
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(d.PH2T + (size_t)n * B + row0 + 4 * g);
             f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gv[i] = (hv[i] > 0.f) ? acc[t][i] : 0.f;
+                gv[i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
                 X2[lds_off(4 * g + i, n, H)] = gv[i];
             }
-            *reinterpret_cast<f32x4 *>(d.dPH2T + (size_t)n * B + row0 + 4 * g) = gv;
+            st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
     __syncthreads();
+    STAMP(3, 4);
     {
         f32x4 acc[4] = {};
-        gemm_tiles<4>(X2, H, 0, H >> 4, PT + d.LP[1].offWt, H, 64 * wave, 16, acc);
+        gemm_ring(r1, X2, H, H >> 4, acc);
+        STAMP(3, 5);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = 64 * wave + 16 * t + c;
-            const f32x4 hv = *reinterpret_cast<const f32x4 *>(d.PH1T + (size_t)n * B + row0 + 4 * g);
             f32x4 gv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gv[i] = (hv[i] > 0.f) ? acc[t][i] : 0.f;
-            *reinterpret_cast<f32x4 *>(d.dPH1T + (size_t)n * B + row0 + 4 * g) = gv;
+            for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
+            st4(d.dPH1T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
+    STAMP(3, 6);
 }
 
 // ------------------------------------------------------------------------------------------
 // K5: weight gradients + Adam + Polyak, tile-owner parallel.  One WG owns a 16 (out) x 64 (in)
 // tile of one layer: dW = sum_b dY[b][n] X[b][k] with the batch split over the 4 waves (MFMA
 // 16x16x4, both operands read feature-major so every lane load is 16 B), reduced through LDS,
-// then the owner applies torch.optim.Adam's update in place, refreshes the transposed copy and
-// (every target_update_period steps) the Polyak average of the target net.  The extra last block
-// computes the step's diagnostics.  The last block to arrive advances the step counters.
+// then the owner applies torch.optim.Adam's update, writes the forward ([n][k]) and transposed
+// ([k][n]) copies of the new weights and (every target_update_period steps) the Polyak average of
+// the target net.  Adam moments live in the transposed layout, so the owner's old weight / m / v
+// are three 16-B loads per lane, issued before the MFMA loop so their latency overlaps it.
+// The work table is a kernel argument (no descriptor load in front of the data loads).
+// The extra last block computes the step's diagnostics.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, float step_size, float bc2s) {
     m = m + (1.0f - ADAM_B1) * (g - m);
@@ -546,173 +743,215 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
     p = p + (-step_size * m) / denom;
 }
 
-__device__ void block_stats(const float *x, int n, int stride, int width, float *out4, double *sh) {
-    // Mean / population Std / Max / Min over x[i*stride + j], i<n, j<width
-    double s = 0.0, s2 = 0.0;
-    float mx = -INFINITY, mn = INFINITY;
-    const int total = n * width;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int i = e / width, j = e - i * width;
-        const float v = x[i * stride + j];
-        s += v; s2 += (double)v * v;
-        mx = fmaxf(mx, v); mn = fminf(mn, v);
-    }
-    __syncthreads();
-    sh[threadIdx.x] = s; sh[256 + threadIdx.x] = s2; sh[512 + threadIdx.x] = mx; sh[768 + threadIdx.x] = mn;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double S = 0, S2 = 0, MX = -INFINITY, MN = INFINITY;
-        for (int i = 0; i < 256; ++i) {
-            S += sh[i]; S2 += sh[256 + i];
-            MX = fmax(MX, sh[512 + i]); MN = fmin(MN, sh[768 + i]);
-        }
-        const double mean = S / total;
-        double var = S2 / total - mean * mean;
-        if (var < 0) var = 0;
-        out4[0] = (float)mean; out4[1] = (float)sqrt(var); out4[2] = (float)MX; out4[3] = (float)MN;
-    }
-    __syncthreads();
-}
+constexpr int NSTAT = 6;     // q1, q2, q_target, log_pi, mu, log_std
 
-__global__ __launch_bounds__(256) void k_dw_adam(Dev d, const DwJob *__restrict__ jobs, int njobs,
-                                                 const float *__restrict__ slots, SlotLayout SL, int n_slots) {
+__global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, int j) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
     __shared__ float redb[4 * 16];
-    __shared__ float s_sc[2];
-    __shared__ unsigned s_last;
     const int B = d.B;
-    const Ctl ctl = *d.ctl;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
-    const float *S = slots + (size_t)(ctl.loop_pos % n_slots) * SL.slot_floats;
+    const Ctl *cp = d.ctl;
 
-    if ((int)blockIdx.x < njobs) {
-        const DwJob J = jobs[blockIdx.x];
-        if (threadIdx.x == 0) {
-            const double t = (double)(ctl.adam_t + 1);
-            const double bc1 = 1.0 - pow((double)ADAM_B1, t), bc2 = 1.0 - pow((double)ADAM_B2, t);
-            s_sc[0] = (float)((double)J.lr / bc1);
-            s_sc[1] = (float)sqrt(bc2);
-        }
-        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)J.k0 * B;
-        const float *YT = J.dYT + (size_t)J.n0 * B;
-        f32x4 acc[4] = {};
-        float bsum = 0.f;
+    if ((int)blockIdx.x < T.njobs) {
+        int li = 0;
+#pragma unroll
+        for (int q = 1; q < NDW; ++q) li = ((int)blockIdx.x >= T.L[q].job0) ? q : li;
+        const DwLayer &J = T.L[li];
+        const int jj = blockIdx.x - J.job0;
+        const int n0 = 16 * (jj / J.nk), k0 = 64 * (jj % J.nk);
+        // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
+        const int k_own = k0 + 16 * wave + r;
+        const bool own_valid = k_own < J.K;
+        const size_t ot = (size_t)k_own * J.ldt + n0 + 4 * g;
+        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)k0 * B;
+        const float *YT = J.dYT + (size_t)n0 * B;
         const int per = (B / 16) / 4;                 // 16-row chunks of the batch per wave
         const int rem = (B / 16) - 4 * per;
         const int s0 = wave * per + (wave < rem ? wave : rem);
         const int s1 = s0 + per + (wave < rem ? 1 : 0);
         const float *yp = YT + (size_t)r * B + 4 * g;
         const float *xp = XT + (size_t)r * B + 4 * g;
-        for (int sI = s0; sI < s1; ++sI) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(yp + 16 * sI);
-            f32x4 b[4];
+        f32x4 acc[4] = {};
+        float bsum = 0.f;
+        // first group of operand loads, then the owner's state, then the scalars: all in flight together
+        f32x4 a[4], b[4][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const f32x4 *>(xp + (size_t)16 * t * B + 16 * sI);
-            bsum += (a[0] + a[1]) + (a[2] + a[3]);
+        for (int u = 0; u < 4; ++u) {
+            const bool on = s0 + u < s1;
+            a[u] = on ? ld4(yp + 16 * (s0 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                b[u][t] = on ? ld4(xp + (size_t)16 * t * B + 16 * (s0 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 p4 = {0.f, 0.f, 0.f, 0.f}, m4 = p4, v4 = p4;
+        if (own_valid) {
+            p4 = ld4(J.PT + ot);
+            m4 = ld4(J.MT + ot);
+            v4 = ld4(J.VT + ot);
+        }
+        const double bc1 = cp->bc1, bc2sd = cp->bc2s;
+        const long long step_now = cp->step_base + j;
+        const bool polyak = (J.TP != nullptr) && (step_now % d.period == 0);
+        f32x4 tp4 = {0.f, 0.f, 0.f, 0.f};
+        if (polyak && own_valid) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                const int n = n0 + 4 * g + i;
+                if (n < J.N) tp4[i] = J.TP[(size_t)n * J.ldp + k_own];
+            }
+        }
+        float pb = 0.f, mbv = 0.f, vbv = 0.f, tbv = 0.f;
+        const bool bias_lane = (k0 == 0) && threadIdx.x < 16 && (n0 + (int)threadIdx.x) < J.N;
+        if (bias_lane) {
+            const int n = n0 + threadIdx.x;
+            pb = J.bias[n]; mbv = J.mb[n]; vbv = J.vb[n];
+            if (polyak) tbv = J.Tbias[n];
+        }
+        for (int sI = s0; sI < s1; sI += 4) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][t][i], acc[t], 0, 0, 0);
+                }
+            }
+            if (sI + 4 < s1) {                       // batches above 256 rows: next group
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool on = sI + 4 + u < s1;
+                    a[u] = on ? ld4(yp + 16 * (sI + 4 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        b[u][t] = on ? ld4(xp + (size_t)16 * t * B + 16 * (sI + 4 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4 *>(red + ((wave * 4 + t) * 64 + lane) * 4) = acc[t];
+        for (int t = 0; t < 4; ++t) st4(red + ((wave * 4 + t) * 64 + lane) * 4, acc[t]);
         bsum += __shfl_xor(bsum, 16);
         bsum += __shfl_xor(bsum, 32);
         if (g == 0) redb[wave * 16 + r] = bsum;
         __syncthreads();
-        const float step_size = s_sc[0], bc2s = s_sc[1];
-        const bool polyak = (J.TP != nullptr) && (ctl.n_train_steps_total % d.period == 0);
-        // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
-        {
+        const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
+        if (own_valid) {
             f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int w = 0; w < 4; ++w) gsum += *reinterpret_cast<const f32x4 *>(red + ((w * 4 + wave) * 64 + lane) * 4);
-            const int k = J.k0 + 16 * wave + r;
-            f32x4 pn = {0.f, 0.f, 0.f, 0.f};
-            bool anyv = false;
+            for (int w = 0; w < 4; ++w) gsum += ld4(red + ((w * 4 + wave) * 64 + lane) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int n = J.n0 + 4 * g + i;
-                if (n < J.N && k < J.K) {
-                    const size_t o = (size_t)n * J.ldp + k;
-                    float p = J.P[o], m = J.M[o], v = J.V[o];
+                const int n = n0 + 4 * g + i;
+                if (n < J.N) {
+                    float p = p4[i], m = m4[i], v = v4[i];
                     adam_update(p, m, v, gsum[i], step_size, bc2s);
-                    J.P[o] = p; J.M[o] = m; J.V[o] = v;
+                    p4[i] = p; m4[i] = m; v4[i] = v;
+                    const size_t o = (size_t)n * J.ldp + k_own;
+                    J.P[o] = p;
                     if (J.G) J.G[o] = gsum[i];
-                    if (polyak) J.TP[o] = J.TP[o] * (1.0f - d.tau) + p * d.tau;
-                    pn[i] = p;
-                    anyv = true;
+                    if (polyak) J.TP[o] = tp4[i] * (1.0f - d.tau) + p * d.tau;
                 }
             }
-            if (J.PT && anyv && k < J.K)
-                *reinterpret_cast<f32x4 *>(J.PT + (size_t)k * J.ldt + J.n0 + 4 * g) = pn;
+            st4(J.PT + ot, p4);
+            st4(J.MT + ot, m4);
+            st4(J.VT + ot, v4);
         }
-        if (J.bias && threadIdx.x < 16) {
-            const int n = J.n0 + threadIdx.x;
-            if (n < J.N) {
-                const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
-                float p = J.bias[n], m = J.mb[n], v = J.vb[n];
-                adam_update(p, m, v, gb, step_size, bc2s);
-                J.bias[n] = p; J.mb[n] = m; J.vb[n] = v;
-                if (J.gb) J.gb[n] = gb;
-                if (polyak) J.Tbias[n] = J.Tbias[n] * (1.0f - d.tau) + p * d.tau;
-            }
+        if (bias_lane) {
+            const int n = n0 + threadIdx.x;
+            const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
+            adam_update(pb, mbv, vbv, gb, step_size, bc2s);
+            J.bias[n] = pb; J.mb[n] = mbv; J.vb[n] = vbv;
+            if (J.gb) J.gb[n] = gb;
+            if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
     } else {
-        // ---- diagnostics block (SURVEY Appendix A line 17) ----
-        double *sh = reinterpret_cast<double *>(red);      // 1024 doubles = 8 KB
-        __shared__ float dg[SAC_DIAG_N];
-        if (threadIdx.x < SAC_DIAG_N) dg[threadIdx.x] = 0.f;
-        __syncthreads();
-        // losses
-        double l1 = 0, l2 = 0, lpl = 0, lal = 0;
+        // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
+        const float alpha = cp->alpha, alpha_loss = cp->alpha_loss;
+        const int loop_pos = cp->loop_base + j;
+        double sm[NSTAT], sq[NSTAT], ls4[4];
+        float mx[NSTAT], mn[NSTAT];
+#pragma unroll
+        for (int q = 0; q < NSTAT; ++q) { sm[q] = 0; sq[q] = 0; mx[q] = -INFINITY; mn[q] = INFINITY; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ls4[q] = 0;
+        auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
         for (int i = threadIdx.x; i < B; i += 256) {
-            const float yv = d.y[i];
-            const float e1 = d.q[i] - yv, e2 = d.q[(size_t)B + i] - yv;
-            l1 += (double)e1 * e1; l2 += (double)e2 * e2;
+            const float yv = d.y[i], q1 = d.q[i], q2 = d.q[(size_t)B + i], lp = d.logpi[i];
+            const float e1 = q1 - yv, e2 = q2 - yv;
             const float qn = fminf(d.q[2 * (size_t)B + i], d.q[3 * (size_t)B + i]);
-            lpl += (double)(d.logpi[i] - qn);
-            lal += (double)(ctl.alpha * d.logpi[i] - qn);
+            ls4[0] += (double)e1 * e1; ls4[1] += (double)e2 * e2;
+            ls4[2] += (double)(lp - qn); ls4[3] += (double)(alpha * lp - qn);
+            acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, lp);
         }
-        sh[threadIdx.x] = l1; sh[256 + threadIdx.x] = l2; sh[512 + threadIdx.x] = lpl; sh[768 + threadIdx.x] = lal;
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            double s = 0;
-            for (int i = 0; i < 256; ++i) s += sh[256 * threadIdx.x + i];
-            dg[SAC_D_QF1_LOSS + threadIdx.x] = (float)(s / B);
+        for (int e = threadIdx.x; e < B * d.A; e += 256) {
+            const int i = e / d.A, jj = e - i * d.A;
+            acc1(4, d.mu[i * 16 + jj]); acc1(5, d.ls[i * 16 + jj]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) {
+                sm[q] += __shfl_xor(sm[q], o); sq[q] += __shfl_xor(sq[q], o);
+                mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o)); mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ls4[q] += __shfl_xor(ls4[q], o);
+        }
+        double *sh = reinterpret_cast<double *>(red);      // [4 waves][32]
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NSTAT; ++q) {
+                sh[wave * 32 + q] = sm[q]; sh[wave * 32 + 6 + q] = sq[q];
+                sh[wave * 32 + 12 + q] = mx[q]; sh[wave * 32 + 18 + q] = mn[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sh[wave * 32 + 24 + q] = ls4[q];
         }
         __syncthreads();
-        block_stats(d.q, B, 1, 1, dg + SAC_D_Q1_MEAN, sh);
-        block_stats(d.q + B, B, 1, 1, dg + SAC_D_Q2_MEAN, sh);
-        block_stats(d.y, B, 1, 1, dg + SAC_D_QT_MEAN, sh);
-        block_stats(d.logpi, B, 1, 1, dg + SAC_D_LOGPI_MEAN, sh);
-        block_stats(d.mu, B, 16, d.A, dg + SAC_D_MU_MEAN, sh);
-        block_stats(d.ls, B, 16, d.A, dg + SAC_D_LOGSTD_MEAN, sh);
-        if (threadIdx.x == 0) { dg[SAC_D_ALPHA] = ctl.alpha; dg[SAC_D_ALPHA_LOSS] = ctl.alpha_loss; }
-        __syncthreads();
-        if (threadIdx.x < SAC_DIAG_N) {
-            const float v = dg[threadIdx.x];
-            d.diag_last[threadIdx.x] = v;
-            if (ctl.loop_pos == 0) d.diag_first[threadIdx.x] = v;
-            if (ctl.loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)ctl.loop_pos * SAC_DIAG_N + threadIdx.x] = v;
+        if (threadIdx.x < NSTAT) {
+            const int q = threadIdx.x;
+            double s = 0, s2 = 0, MX = -INFINITY, MN = INFINITY;
+            for (int w = 0; w < 4; ++w) {
+                s += sh[w * 32 + q]; s2 += sh[w * 32 + 6 + q];
+                MX = fmax(MX, sh[w * 32 + 12 + q]); MN = fmin(MN, sh[w * 32 + 18 + q]);
+            }
+            const double cnt = (q < 4) ? (double)B : (double)B * d.A;
+            const double mean = s / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0) var = 0;
+            const float o4[4] = {(float)mean, (float)sqrt(var), (float)MX, (float)MN};
+            for (int u = 0; u < 4; ++u) {
+                const int di = SAC_D_Q1_MEAN + 4 * q + u;
+                d.diag_last[di] = o4[u];
+                if (loop_pos == 0) d.diag_first[di] = o4[u];
+                if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = o4[u];
+            }
+        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + 8) {
+            const int q = threadIdx.x - 64;        // 0..3 losses, 4 alpha, 5 alpha loss, 6/7 unused
+            float v = 0.f;
+            int di = SAC_D_QF1_LOSS + q;
+            if (q < 4) {
+                double s = 0;
+                for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24 + q];
+                v = (float)(s / B);
+            } else if (q == 4) { v = alpha; di = SAC_D_ALPHA; }
+            else if (q == 5) { v = alpha_loss; di = SAC_D_ALPHA_LOSS; }
+            else { di = 30 + (q - 6); }
+            d.diag_last[di] = v;
+            if (loop_pos == 0) d.diag_first[di] = v;
+            if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
         }
     }
-    // ---- last arriver advances the counters (every block has read ctl by now) ----
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned tk = atomicAdd(&d.ctl->ticket, 1u);
-        s_last = (tk == (unsigned)njobs) ? 1u : 0u;
-        if (s_last) {
-            d.ctl->ticket = 0u;
-            d.ctl->n_train_steps_total = ctl.n_train_steps_total + 1;
-            d.ctl->adam_t = ctl.adam_t + 1;
-            d.ctl->loop_pos = ctl.loop_pos + 1;
-            __threadfence();
-        }
+}
+
+// end of a chunk of n steps: advance the device-side counters (in stream order)
+__global__ void k_advance(Ctl *c, int n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        c->step_base += n;
+        c->adam_base += n;
+        c->loop_base += n;
     }
 }
 
@@ -730,7 +969,7 @@ struct sac_trainer {
     int B = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0;
     Net net[5];
     Dev dev{};
-    DwJob *d_jobs = nullptr; int njobs = 0;
+    DwTable dw{};
     float *ws = nullptr; int64_t ws_floats = 0;      // all activations / gradients
     float *ext_slot = nullptr; SlotLayout ext_layout{};
     float *d_eps = nullptr;                           // [2][B*A]
@@ -810,84 +1049,56 @@ int ensure_stage_t(sac_trainer *t, size_t bytes) {
     return 0;
 }
 
-int launch_step(sac_trainer *t, const float *slots, const SlotLayout &SL, int n_slots) {
+// the five launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
+// between the launches (profiling pass only)
+int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr) {
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
     const int NB = t->NB;
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_fwd<1>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
-    else hipLaunchKernelGGL(k_policy_fwd<2>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
-    hipLaunchKernelGGL(k_q_fwd, dim3(6 * NB), dim3(256), t->lds_qf, s, d, slots, SL, n_slots);
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, slots, SL, n_slots);
+    if (ev) SAC_HIP(hipEventRecord(ev[0], s));
+    if (t->NH == 16) hipLaunchKernelGGL(k_policy_fwd<1>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
+    else hipLaunchKernelGGL(k_policy_fwd<2>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
+    if (ev) SAC_HIP(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(k_q_fwd, dim3(6 * NB + 1), dim3(256), t->lds_qf, s, d, S, SL, j);
+    if (ev) SAC_HIP(hipEventRecord(ev[2], s));
+    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, S, SL, j);
+    if (ev) SAC_HIP(hipEventRecord(ev[3], s));
     if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
     else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
-    hipLaunchKernelGGL(k_dw_adam, dim3(t->njobs + 1), dim3(256), 0, s, d, t->d_jobs, t->njobs, slots, SL, n_slots);
+    if (ev) SAC_HIP(hipEventRecord(ev[4], s));
+    hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, j);
+    if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
     SAC_HIP(hipGetLastError());
     return 0;
 }
 
-// same five launches with HIP events between them (profiling pass only)
-int launch_step_timed(sac_trainer *t, const float *slots, const SlotLayout &SL, int n_slots, hipEvent_t *ev) {
-    const Dev &d = t->dev;
-    hipStream_t s = t->stream;
-    const int NB = t->NB;
-    SAC_HIP(hipEventRecord(ev[0], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_fwd<1>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
-    else hipLaunchKernelGGL(k_policy_fwd<2>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, slots, SL, n_slots);
-    SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k_q_fwd, dim3(6 * NB), dim3(256), t->lds_qf, s, d, slots, SL, n_slots);
-    SAC_HIP(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, slots, SL, n_slots);
-    SAC_HIP(hipEventRecord(ev[3], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
-    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
-    SAC_HIP(hipEventRecord(ev[4], s));
-    hipLaunchKernelGGL(k_dw_adam, dim3(t->njobs + 1), dim3(256), 0, s, d, t->d_jobs, t->njobs, slots, SL, n_slots);
-    SAC_HIP(hipEventRecord(ev[5], s));
+int begin_loop(sac_trainer *t) {
+    int zero = 0;
+    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_base, &zero, sizeof(int), hipMemcpyHostToDevice, t->stream));
+    return 0;
+}
+
+int advance(sac_trainer *t, int n) {
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, t->stream, t->d_ctl, n);
     SAC_HIP(hipGetLastError());
     return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[8]) {
-    SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
-    SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
-    SAC_HIP(hipSetDevice(t->device));
-    hipStream_t s = t->stream;
-    t->dev.eps1 = t->dev.eps2 = nullptr;
+// sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
+int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
     if (ensure_slots(b, t->B, n_steps)) return -1;
     SAC_HIP(hipEventRecord(b->ev[0], b->stream));
     if (launch_sample(b, t->B, n_steps)) return -1;
     SAC_HIP(hipEventRecord(b->ev[1], b->stream));
     if (launch_gather(b, b->d_idx, t->B, n_steps, b->d_slots, b->slot, 1)) return -1;
     SAC_HIP(hipEventRecord(b->ev[2], b->stream));
-    SAC_HIP(hipStreamWaitEvent(s, b->ev[2], 0));
-    int zero = 0;
-    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_pos, &zero, sizeof(int), hipMemcpyHostToDevice, s));
-    std::vector<hipEvent_t> ev((size_t)n_steps * 6);
-    for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
-    for (int64_t i = 0; i < n_steps; ++i)
-        if (launch_step_timed(t, b->d_slots, b->slot, (int)n_steps, &ev[(size_t)i * 6])) return -1;
-    SAC_HIP(hipStreamSynchronize(s));
-    double acc[5] = {0, 0, 0, 0, 0};
-    for (int64_t i = 0; i < n_steps; ++i)
-        for (int k = 0; k < 5; ++k) {
-            float ms = 0.f;
-            SAC_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 6 + k], ev[(size_t)i * 6 + k + 1]));
-            acc[k] += ms;
-        }
-    float tot = 0.f;
-    SAC_HIP(hipEventElapsedTime(&tot, ev[0], ev[(size_t)n_steps * 6 - 1]));
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    SAC_HIP(hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
-    SAC_HIP(hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
-    for (int k = 0; k < 5; ++k) out_ms[2 + k] = (float)(acc[k] / (double)n_steps);
-    out_ms[7] = tot;
-    t->mirror_valid = false;
+    SAC_HIP(hipStreamWaitEvent(t->stream, b->ev[2], 0));
     return 0;
 }
+
+}  // namespace
+
+extern "C" {
 
 int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     SAC_REQUIRE(out && cfg, "null argument to sac_trainer_create");
@@ -917,7 +1128,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
         if (alloc_zero(&n.P, n.nP, s)) return -1;
         if (i < 3) {
             if (alloc_zero(&n.M, n.nP, s) || alloc_zero(&n.V, n.nP, s) || alloc_zero(&n.PT, n.nPT, s) ||
-                alloc_zero(&n.G, n.nP, s)) return -1;
+                alloc_zero(&n.MT, n.nPT, s) || alloc_zero(&n.VT, n.nPT, s) || alloc_zero(&n.G, n.nP, s)) return -1;
         }
     }
     // workspace carve
@@ -954,27 +1165,26 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     d.diag_first = t->d_diag; d.diag_last = t->d_diag + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
     d.eps1 = d.eps2 = nullptr;
 
-    // weight-gradient job table
-    std::vector<DwJob> jobs;
+    // weight-gradient work table: the 256x256 layers first (longest jobs)
+    int nl = 0, job = 0;
     auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr) {
         Net &n = t->net[netid];
         const Layer &L = n.L[l];
-        for (int n0 = 0; n0 < L.Np; n0 += 16)
-            for (int k0 = 0; k0 < L.Kp; k0 += 64) {
-                DwJob j{};
-                j.dYT = dYT; j.XT = XT; j.xt_from_slot = from_slot; j.xt_off = t->ext_layout.off_saT;
-                j.P = n.P + L.offW; j.M = n.M + L.offW; j.V = n.V + L.offW; j.G = n.G + L.offW;
-                j.PT = n.PT + L.offWt;
-                j.ldp = L.Kp; j.ldt = L.Np; j.N = L.N; j.K = L.K; j.n0 = n0; j.k0 = k0; j.lr = lr;
-                if (k0 == 0) { j.bias = n.P + L.offB; j.mb = n.M + L.offB; j.vb = n.V + L.offB; j.gb = n.G + L.offB; }
-                if (netid == 1 || netid == 2) {
-                    j.TP = t->net[netid + 2].P + L.offW;
-                    j.Tbias = t->net[netid + 2].P + L.offB;
-                }
-                jobs.push_back(j);
-            }
+        DwLayer &J = t->dw.L[nl++];
+        J.dYT = dYT; J.XT = XT; J.xt_from_slot = from_slot; J.xt_off = t->ext_layout.off_saT;
+        J.P = n.P + L.offW; J.G = n.G + L.offW;
+        J.PT = n.PT + L.offWt; J.MT = n.MT + L.offWt; J.VT = n.VT + L.offWt;
+        J.bias = n.P + L.offB; J.mb = n.M + L.offB; J.vb = n.V + L.offB; J.gb = n.G + L.offB;
+        J.TP = nullptr; J.Tbias = nullptr;
+        if (netid == 1 || netid == 2) {
+            J.TP = t->net[netid + 2].P + L.offW;
+            J.Tbias = t->net[netid + 2].P + L.offB;
+        }
+        J.ldp = L.Kp; J.ldt = L.Np; J.N = L.N; J.K = L.K; J.lr = lr;
+        J.nk = (L.Kp + 63) / 64;
+        J.job0 = job;
+        job += (L.Np / 16) * J.nk;
     };
-    // big (256x256) layers first: they are the longest jobs
     add_layer(0, 1, d.dPH2T, d.PH1T, 0, cfg->policy_lr);
     add_layer(1, 1, d.dQH2T, d.QH1T, 0, cfg->qf_lr);
     add_layer(2, 1, d.dQH2T + (size_t)H * B, d.QH1T + (size_t)H * B, 0, cfg->qf_lr);
@@ -984,9 +1194,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     add_layer(0, 2, d.dheadT, d.PH2T, 0, cfg->policy_lr);
     add_layer(1, 2, d.dq16T, d.QH2T, 0, cfg->qf_lr);
     add_layer(2, 2, d.dq16T + (size_t)16 * B, d.QH2T + (size_t)H * B, 0, cfg->qf_lr);
-    t->njobs = (int)jobs.size();
-    SAC_HIP(hipMalloc(&t->d_jobs, sizeof(DwJob) * jobs.size()));
-    SAC_HIP(hipMemcpyAsync(t->d_jobs, jobs.data(), sizeof(DwJob) * jobs.size(), hipMemcpyHostToDevice, s));
+    t->dw.njobs = job;
 
     const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
@@ -1006,9 +1214,9 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     (void)hipSetDevice(t->device);
     (void)hipStreamSynchronize(t->stream);
     for (auto &n : t->net)
-        for (float *p : {n.P, n.M, n.V, n.PT, n.G}) (void)hipFree(p);
+        for (float *p : {n.P, n.M, n.V, n.PT, n.MT, n.VT, n.G}) (void)hipFree(p);
     (void)hipFree(t->ws); (void)hipFree(t->ext_slot); (void)hipFree(t->d_eps); (void)hipFree(t->d_diag);
-    (void)hipFree(t->d_ctl); (void)hipFree(t->d_jobs);
+    (void)hipFree(t->d_ctl);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
@@ -1021,8 +1229,9 @@ int64_t sac_param_count(const sac_trainer_t *t, int net) {
     return flat_count(flat_map(t, net));
 }
 
-static int upload_padded(sac_trainer *t, int net, const float *flat, float *devbuf, bool also_transposed) {
+static int upload_padded(sac_trainer *t, int net, const float *flat, float *devbuf, float *devT) {
     Net &n = t->net[net];
+    const bool also_transposed = devT != nullptr;
     std::vector<float> P((size_t)n.nP, 0.f), PT;
     if (also_transposed) PT.assign((size_t)n.nPT, 0.f);
     for_each_param(t, net, [&](int64_t fi, int l, int nn, int k, bool is_b) {
@@ -1035,19 +1244,25 @@ static int upload_padded(sac_trainer *t, int net, const float *flat, float *devb
     });
     SAC_HIP(hipMemcpyAsync(devbuf, P.data(), sizeof(float) * P.size(), hipMemcpyHostToDevice, t->stream));
     if (also_transposed)
-        SAC_HIP(hipMemcpyAsync(n.PT, PT.data(), sizeof(float) * PT.size(), hipMemcpyHostToDevice, t->stream));
+        SAC_HIP(hipMemcpyAsync(devT, PT.data(), sizeof(float) * PT.size(), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
     return 0;
 }
 
-static int download_padded(sac_trainer *t, int net, const float *devbuf, float *flat) {
+// weights come from the transposed buffer when devT is given (Adam moments), else from devbuf
+static int download_padded(sac_trainer *t, int net, const float *devbuf, float *flat, const float *devT = nullptr) {
     Net &n = t->net[net];
-    std::vector<float> P((size_t)n.nP);
+    std::vector<float> P((size_t)n.nP), PT;
     SAC_HIP(hipMemcpyAsync(P.data(), devbuf, sizeof(float) * P.size(), hipMemcpyDeviceToHost, t->stream));
+    if (devT) {
+        PT.resize((size_t)n.nPT);
+        SAC_HIP(hipMemcpyAsync(PT.data(), devT, sizeof(float) * PT.size(), hipMemcpyDeviceToHost, t->stream));
+    }
     SAC_HIP(hipStreamSynchronize(t->stream));
     for_each_param(t, net, [&](int64_t fi, int l, int nn, int k, bool is_b) {
         const Layer &L = n.L[l];
-        flat[fi] = is_b ? P[L.offB + nn] : P[L.offW + (size_t)nn * L.Kp + k];
+        if (is_b) flat[fi] = P[L.offB + nn];
+        else flat[fi] = devT ? PT[L.offWt + (size_t)k * L.Np + nn] : P[L.offW + (size_t)nn * L.Kp + k];
     });
     return 0;
 }
@@ -1058,7 +1273,7 @@ int sac_set_params(sac_trainer_t *t, int net, const float *flat, int64_t n) {
                 (long long)sac_param_count(t, net), (long long)n);
     SAC_HIP(hipSetDevice(t->device));
     t->mirror_valid = false;
-    return upload_padded(t, net, flat, t->net[net].P, net < 3);
+    return upload_padded(t, net, flat, t->net[net].P, net < 3 ? t->net[net].PT : nullptr);
 }
 
 int sac_get_params(sac_trainer_t *t, int net, float *flat, int64_t n) {
@@ -1073,16 +1288,16 @@ int sac_set_opt_state(sac_trainer_t *t, int net, const float *m, const float *v,
     SAC_REQUIRE(t && m && v && net >= 0 && net <= 2, "bad arguments to sac_set_opt_state (trained nets are 0..2)");
     SAC_REQUIRE(n == sac_param_count(t, net), "size mismatch in sac_set_opt_state");
     SAC_HIP(hipSetDevice(t->device));
-    if (upload_padded(t, net, m, t->net[net].M, false)) return -1;
-    return upload_padded(t, net, v, t->net[net].V, false);
+    if (upload_padded(t, net, m, t->net[net].M, t->net[net].MT)) return -1;
+    return upload_padded(t, net, v, t->net[net].V, t->net[net].VT);
 }
 
 int sac_get_opt_state(sac_trainer_t *t, int net, float *m, float *v, int64_t n) {
     SAC_REQUIRE(t && m && v && net >= 0 && net <= 2, "bad arguments to sac_get_opt_state (trained nets are 0..2)");
     SAC_REQUIRE(n == sac_param_count(t, net), "size mismatch in sac_get_opt_state");
     SAC_HIP(hipSetDevice(t->device));
-    if (download_padded(t, net, t->net[net].M, m)) return -1;
-    return download_padded(t, net, t->net[net].V, v);
+    if (download_padded(t, net, t->net[net].M, m, t->net[net].MT)) return -1;
+    return download_padded(t, net, t->net[net].V, v, t->net[net].VT);
 }
 
 int sac_set_scalars(sac_trainer_t *t, const double sc[6]) {
@@ -1091,7 +1306,7 @@ int sac_set_scalars(sac_trainer_t *t, const double sc[6]) {
     Ctl c;
     memset(&c, 0, sizeof(c));
     c.log_alpha = (float)sc[0]; c.a_m = (float)sc[1]; c.a_v = (float)sc[2];
-    c.adam_t = (long long)sc[3]; c.n_train_steps_total = (long long)sc[4];
+    c.adam_base = (long long)sc[3]; c.step_base = (long long)sc[4];
     c.alpha = t->cfg.use_automatic_entropy_tuning ? expf(c.log_alpha) : 1.0f;
     SAC_HIP(hipMemcpyAsync(t->d_ctl, &c, sizeof(c), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
@@ -1104,8 +1319,8 @@ int sac_get_scalars(sac_trainer_t *t, double sc[6]) {
     Ctl c;
     SAC_HIP(hipMemcpyAsync(&c, t->d_ctl, sizeof(c), hipMemcpyDeviceToHost, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    sc[0] = c.log_alpha; sc[1] = c.a_m; sc[2] = c.a_v; sc[3] = (double)c.adam_t;
-    sc[4] = (double)c.n_train_steps_total; sc[5] = c.alpha;
+    sc[0] = c.log_alpha; sc[1] = c.a_m; sc[2] = c.a_v; sc[3] = (double)c.adam_base;
+    sc[4] = (double)c.step_base; sc[5] = c.alpha;
     return 0;
 }
 
@@ -1145,9 +1360,9 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     } else {
         t->dev.eps1 = t->dev.eps2 = nullptr;
     }
-    int zero = 0;
-    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_pos, &zero, sizeof(int), hipMemcpyHostToDevice, s));
-    if (launch_step(t, t->ext_slot, L, 1)) return -1;
+    if (begin_loop(t)) return -1;
+    if (launch_step(t, t->ext_slot, L, 0)) return -1;
+    if (advance(t, 1)) return -1;
     if (diag) SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
     t->mirror_valid = false;
@@ -1155,27 +1370,20 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
 }
 
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
-    SAC_REQUIRE(t && b && n_steps > 0, "bad arguments to sac_train_loop");
+    SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
     SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");
     SAC_REQUIRE(b->O == t->O && b->A == t->A, "buffer dims (%d,%d) do not match trainer dims (%d,%d)", b->O, b->A,
                 t->O, t->A);
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    // 1) indices for every step, 2) one gather launch -> slots; both on the buffer's stream
-    if (ensure_slots(b, t->B, n_steps)) return -1;
-    SAC_HIP(hipEventRecord(b->ev[0], b->stream));
-    if (launch_sample(b, t->B, n_steps)) return -1;
-    SAC_HIP(hipEventRecord(b->ev[1], b->stream));
-    if (launch_gather(b, b->d_idx, t->B, n_steps, b->d_slots, b->slot, 1)) return -1;
-    SAC_HIP(hipEventRecord(b->ev[2], b->stream));
-    SAC_HIP(hipStreamWaitEvent(s, b->ev[2], 0));
-    // 3) the steps
-    int zero = 0;
-    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_pos, &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    // 1) indices for every step, 2) one gather launch -> slots (buffer's stream), 3) the steps
+    if (stage_batches(t, b, n_steps)) return -1;
+    if (begin_loop(t)) return -1;
     SAC_HIP(hipEventRecord(t->ev[0], s));
     for (int64_t i = 0; i < n_steps; ++i)
-        if (launch_step(t, b->d_slots, b->slot, (int)n_steps)) return -1;
+        if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i)) return -1;
+    if (advance(t, (int)n_steps)) return -1;
     SAC_HIP(hipEventRecord(t->ev[1], s));
     if (diag_first) SAC_HIP(hipMemcpyAsync(diag_first, t->dev.diag_first, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     if (diag_last) SAC_HIP(hipMemcpyAsync(diag_last, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
@@ -1184,6 +1392,44 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipEventElapsedTime(&t->last_ms[2], b->ev[1], b->ev[2]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[0], b->ev[0], t->ev[1]));
+    t->mirror_valid = false;
+    return 0;
+}
+
+int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[8]) {
+    SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
+    SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
+    SAC_HIP(hipSetDevice(t->device));
+    hipStream_t s = t->stream;
+    t->dev.eps1 = t->dev.eps2 = nullptr;
+    if (stage_batches(t, b, n_steps)) return -1;
+    if (begin_loop(t)) return -1;
+    std::vector<hipEvent_t> ev((size_t)n_steps * 7);
+    for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
+    for (int64_t i = 0; i < n_steps; ++i)
+        if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * 7])) return -1;
+    if (advance(t, (int)n_steps)) return -1;
+    SAC_HIP(hipStreamSynchronize(s));
+    // interval k = launch k between two event records; the empty interval ev[5]->ev[6] measures what
+    // an event pair costs by itself and is subtracted
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n_steps; ++i)
+        for (int k = 0; k < 6; ++k) {
+            float ms = 0.f;
+            SAC_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 7 + k], ev[(size_t)i * 7 + k + 1]));
+            acc[k] += ms;
+        }
+    float tot = 0.f;
+    SAC_HIP(hipEventElapsedTime(&tot, ev[0], ev[(size_t)n_steps * 7 - 1]));
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    SAC_HIP(hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
+    SAC_HIP(hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
+    const double empty = acc[5] / (double)n_steps;
+    for (int k = 0; k < 5; ++k) {
+        const double v = acc[k] / (double)n_steps - empty;
+        out_ms[2 + k] = (float)(v > 0 ? v : 0);
+    }
+    out_ms[7] = tot;
     t->mirror_valid = false;
     return 0;
 }
@@ -1254,6 +1500,15 @@ int64_t sac_debug_fetch(sac_trainer_t *t, const char *name, float *out, int64_t 
     sac::set_error("unknown debug tensor '%s'", name);
     return -2;
 }
+
+#ifdef SAC_STAMPS
+int sac_fetch_stamps(sac_trainer_t *t, unsigned long long *out) {
+    SAC_HIP(hipSetDevice(t->device));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    SAC_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(sac::g_stamps), sizeof(unsigned long long) * 5 * 512 * 16));
+    return 0;
+}
+#endif
 
 int sac_policy_mirror(sac_trainer_t *t) {
     SAC_REQUIRE(t, "null trainer");
