@@ -26,9 +26,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from robosuite_benchmark_amd import parallel  # noqa: E402
+
 H = 256
-SWEEP = [("Lift", 42, 7), ("Door", 46, 7), ("Stack", 55, 7), ("Wipe", 379, 6), ("PickPlaceCan", 46, 7),
-         ("NutAssemblyRound", 46, 7), ("TwoArmPegInHole", 73, 12), ("TwoArmHandoff", 86, 14)]
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
@@ -38,8 +38,7 @@ def flops_per_kernel(B, O, A):
     P = O * H + H * H + 2 * H * A              # policy MACs / sample
     Q = (O + A) * H + H * H + H                # Q MACs / sample
     return {
-        "k_policy_fwd": 2 * B * 2 * P,                                   # pi(s), pi(s')
-        "k_q_fwd": 2 * B * 6 * Q,                                        # six Q passes
+        "k_fwd": 2 * B * (2 * P + 6 * Q),                                # pi(s), pi(s') and six Q passes
         "k_q_bwd": 2 * B * (2 * (H + H * H) + 2 * (H + H * H + A * H)),  # critic dX (2 nets) + actor dX (2 nets)
         "k_policy_bwd": 2 * B * (2 * A * H + H * H),                     # head^T, fc1^T
         "k_dw_adam": 2 * B * (2 * Q + P),                                # dW of two critics + policy
@@ -142,9 +141,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=500)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = parallel.rank_info()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -153,14 +150,11 @@ def main():
     import torch
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        dist = parallel.init_process_group("nccl", local_rank)      # nccl == RCCL on ROCm
 
-    task, O, A = SWEEP[rank % len(SWEEP)] if (args.sweep and world > 1) else SWEEP[0]
+    task, O, A, seed = parallel.task_for_rank(rank, sweep=args.sweep and world > 1)
     B = args.batch
-    trainer, buf = build_replica(task, O, A, B, args.buffer, seed=17 + rank, device=local_rank)
+    trainer, buf = build_replica(task, O, A, B, args.buffer, seed=seed, device=local_rank)
 
     def barrier():
         if dist is not None:
@@ -178,23 +172,13 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms = trainer.loop_timing_ms()
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed_max = float(tmax.item())
-        # the only collective of the job: per-GPU result vectors (steps/s, last losses) all-gathered
-        mine = torch.tensor([args.steps / elapsed, float(last[0]), float(last[1]), float(last[28])], device="cuda",
-                            dtype=torch.float64)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_gpu = [[float(x) for x in r.tolist()] for r in allr]
-    else:
-        elapsed_max = elapsed
-        per_gpu = [[args.steps / elapsed, float(last[0]), float(last[1]), float(last[28])]]
+    elapsed_max = parallel.max_over_ranks(dist, elapsed)
+    # the only collective of the job: per-GPU result vectors (steps/s, last losses, alpha) all-gathered
+    per_gpu = parallel.gather_results(dist, [args.steps / elapsed, float(last[0]), float(last[1]), float(last[28])])
 
     out = None
     if rank == 0:
-        value = world * args.steps / elapsed_max
+        value = parallel.aggregate_steps_per_second(world, args.steps, elapsed_max)
         # ---- per-kernel durations: instrumented replay of the same loop (HIP events on the
         #      launching streams), N=1 / rank 0 only ------------------------------------------
         prof = trainer.profile_loop(buf, min(args.profile_steps, args.steps, 4096), batch_size=B)

@@ -11,11 +11,10 @@
 // grid barrier on 8 XCDs); the weight-gradient kernel is tile-owner parallel and applies Adam and
 // the Polyak update in its epilogue, so gradients never round-trip through HBM.
 //
-//   K1 k_policy_fwd   2*B/16 WGs   pi(s), pi(s') : 3 layers + tanh-Gaussian head, log_pi
-//   K2 k_q_fwd        6*B/16+1     Q1,Q2 on (s,a), (s,a_new); T1,T2 on (s',a')  (+ alpha Adam step)
-//   K3 k_q_bwd        4*B/16 WGs   critic dL/dh (2 nets), actor dQ/da (2 nets)
-//   K4 k_policy_bwd     B/16 WGs   head gradient (reparameterised), dL/dh
-//   K5 k_dw_adam      ~250  WGs    dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
+//   K1 k_fwd          6*B/16 WGs   pi(s) -> Q1,Q2(s,a_new); pi(s') -> T1,T2(s',a'); Q1,Q2(s,a); alpha step
+//   K2 k_q_bwd        4*B/16 WGs   critic dL/dh (2 nets), actor dQ/da (2 nets)
+//   K3 k_policy_bwd     B/16 WGs   head gradient (reparameterised), dL/dh
+//   K4 k_dw_adam      ~250  WGs    dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
 //
 // Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round
 // trips, not by FLOPs): the minibatch slot and the step index are launch arguments (no dependent
@@ -48,7 +47,8 @@ struct Ctl {                       // device-resident step state
     long long adam_base;           // optimizer step count at the start of the current chunk
     int loop_base;                 // steps of the current sac_train_loop already finished
     float log_alpha, a_m, a_v, alpha, alpha_loss;
-    int pad[2];
+    unsigned ticket;               // arrival counter of the forward kernel's owner blocks
+    int pad[1];
     double bc1, bc2s;              // 1 - beta1^t, sqrt(1 - beta2^t) of the CURRENT step (K2 writes)
 };
 
@@ -134,13 +134,9 @@ __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4
 // register ring.  W is [n][ldw] (ldw % 4 == 0); lane (c = lane&15, g = lane>>4) loads the 16 B
 // W[n0_t + c][16 S + 4 g .. +3], i.e. lane group g owns contraction index k = 16S + 4g + i.
 #ifndef SAC_ROT
-#define SAC_ROT(b) (((b) >> 3) * 4)
+#define SAC_ROT(b) (((b) >> 3) * 4)      // blocks b, b+8, ... usually share an XCD (speed only)
 #endif
-#ifdef SAC_EXPERIMENT_CONTIG
-#define CHUNK_STRIDE 256
-#else
 #define CHUNK_STRIDE 16
-#endif
 template <int NT, int D = RD>
 struct WRing {
     f32x4 b[D][NT];
@@ -155,12 +151,7 @@ struct WRing {
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-#ifdef SAC_EXPERIMENT_CONTIG
-            wp[t] = (ldw == H) ? W + ((size_t)((n_base >> 4) + t) * (H / 16) * 64 + lane) * 4 - (size_t)16 * 0
-                               : W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
-#else
             wp[t] = W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
-#endif
     }
     __device__ __forceinline__ void fill(int KS) {        // chunks 0 .. min(D, KS)-1 into flight
 #pragma unroll
@@ -278,14 +269,15 @@ struct RowRegs {
             }
         }
     }
-    __device__ __forceinline__ void commit(float *X, int KL, int Kfill) const {
+    // columns [skip_lo, skip_hi) are left to another writer (the policy head's action)
+    __device__ __forceinline__ void commit(float *X, int KL, int Kfill, int skip_lo = 0, int skip_hi = 0) const {
         const int nper = Kfill >> 4;
 #pragma unroll
         for (int i = 0; i < ROWS_MAXE; ++i)
             if (i < nper) {
                 const int e = threadIdx.x + 256 * i;
                 const int row = e / Kfill, k = e - row * Kfill;
-                X[lds_off(row, k, KL)] = v[i];
+                if (k < skip_lo || k >= skip_hi) X[lds_off(row, k, KL)] = v[i];
             }
     }
 };
@@ -311,201 +303,206 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: policy forward on s (blocks [0,NB)) and s' (blocks [NB,2NB))
+// K1: the whole forward pass.  pass = blockIdx / NB, one 16-row block each:
+//   0 Q1(s,a)   1 Q2(s,a)   2 pi(s) -> Q1(s,a_new)   3 pi(s) -> Q2(s,a_new)
+//   4 pi(s') -> T1(s',a')   5 pi(s') -> T2(s',a')
+// Rows are independent, so a block that needs the policy's action for its rows simply runs the
+// policy for those rows itself (passes 3 and 5 repeat the tiny policy forward of passes 2 and 4
+// bit-for-bit; only the owner passes 2 / 4 write the policy's outputs).  That removes the kernel
+// boundary + cold-cache round trip between "policy forward" and "Q forward".  The weights of the
+// second network are requested while the first one is still computing.
+// The last owner block to finish (arrival ticket, release/acquire at agent scope, no spinning)
+// reduces sum(log_pi) in a fixed order and performs the alpha Adam step (SURVEY Appendix A
+// lines 4-6); it also publishes this step's Adam bias corrections for the weight-gradient kernel.
 // ------------------------------------------------------------------------------------------
 template <int NTH>
-__global__ __launch_bounds__(256) void k_policy_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
+__global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A;
-    const int KL0 = (d.KP + 63) & ~63;
-    float *X0 = lds;                     // [16][KL0]
-    float *X1 = X0 + RB * KL0;           // [16][256]
+    const int KLP = (d.KP + 63) & ~63, KLQ = (d.KQ + 63) & ~63;
+    float *XP = lds;                     // [16][KLP]  policy input row-block
+    float *XQ = XP + RB * KLP;           // [16][KLQ]  Q input row-block cat(obs, action)
+    float *X1 = XQ + RB * KLQ;           // [16][256]
     float *X2 = X1 + RB * H;             // [16][256]
     float *HD = X2 + RB * H;             // [16][32]
     float *red = HD + RB * 32;           // split-K scratch 4*NTH*256
-    const bool next = blockIdx.x >= (unsigned)d.NB;
-    const int rb = next ? blockIdx.x - d.NB : blockIdx.x;
+    const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
     const int row0 = rb * RB;
+    const bool has_pi = pass >= 2, next = pass >= 4, owner = (pass == 2) || (pass == 4);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
-    const float *P = d.P[0];
+    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
+    const float *PP = d.P[0];
+    const float *PQ = d.P[(pass < 4) ? 1 + (pass & 1) : 3 + (pass & 1)];
+    const float *obs = S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
     const long long step_base = d.ctl->step_base;          // used only by the noise counter, much later
 
-    // ---- everything this block will need from memory, requested up front, in consumption order ----
     WRing<4> r0;
     WRing<4, RDH4> r1;
     WRing<NTH> rh;
     RowRegs rows;
-    rows.issue(d.KP, S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
-    r0.init(P + d.LP[0].offW, d.LP[0].Kp, 64 * wave, 16);
-    r0.fill(d.KP >> 4);
-    float bv0[4], bv1[4];
+    float bv0[4], bv1[4], w3[16], b3 = 0.f;
+    auto issue_q_first = [&]() {       // Q net: input rows, first layer, its bias
+        rows.issue(d.KQ, obs, O, O, S + SL.off_act + (size_t)row0 * A, (pass < 2) ? A : 0, A);
+        r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
+        r0.fill(d.KQ >> 4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bv0[t] = P[d.LP[0].offB + 64 * wave + 16 * t + c];
-    SB();
-    r1.init(P + d.LP[1].offW, H, 64 * wave, 16);
-    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
-    r1.fill(H >> 4);
+        for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    };
+    auto issue_q_second = [&]() {      // Q net: hidden layer stream, biases, output layer
+        r1.init(PQ + d.LQ[1].offW, H, 64 * wave, 16);
+        r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+        r1.fill(H >> 4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bv1[t] = P[d.LP[1].offB + 64 * wave + 16 * t + c];
-    rh.init(P + d.LP[2].offW, H, 0, 16, 4 * wave);        // head: contraction split over the waves
-    SB();
-    rows.commit(X0, KL0, d.KP);
-    __syncthreads();
-    {
-        f32x4 acc[4] = {};
-        gemm_ring(r0, X0, KL0, d.KP >> 4, acc);
-        rh.fill(4);
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, next ? nullptr : d.PH1T, B, row0);
-    }
-    __syncthreads();
-    {
-        f32x4 acc[4] = {};
-        gemm_ring(r1, X1, H, H >> 4, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, next ? nullptr : d.PH2T, B, row0);
-    }
-    __syncthreads();
-    {
-        f32x4 acc[NTH] = {};
-        gemm_ring(rh, X2, H, 4, acc, 4 * wave);
-        splitk_reduce<NTH>(acc, P + d.LP[2].offB, red, HD, 32);
-    }
-    // tanh-Gaussian head: thread = (row, a)
-    const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
-    const int grow = row0 + row;
-    float lp = 0.f;
-    if (a < A) {
-        const float mean = HD[row * 32 + a];
-        const float raw = HD[row * 32 + A + a];
-        const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float stdv = expf(lstd);
-        const float *epp = next ? d.eps2 : d.eps1;
-        const float eps = epp ? epp[grow * A + a]
-                              : philox_normal(d.noise_seed, (unsigned long long)(step_base + j),
-                                              (unsigned)(grow * 16 + a), next ? 1u : 0u);
-        const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
-        const float act = tanhf(zz);
-        const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
-        const float var = __fmul_rn(stdv, stdv);
-        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
-        lp = nlp - logf(1.0f - act * act + TANH_EPS);
-        if (!next) {
-            d.mu[grow * 16 + a] = mean;
-            d.ls[grow * 16 + a] = lstd;
-            d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
-            d.z[grow * 16 + a] = zz;
-            d.anew[grow * 16 + a] = act;
-            d.epsv[grow * 16 + a] = eps;
-        } else {
-            d.a2[grow * 16 + a] = act;
+        for (int t = 0; t < 4; ++t) bv1[t] = PQ[d.LQ[1].offB + 64 * wave + 16 * t + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w3[u] = PQ[d.LQ[2].offW + part + 16 * u];
+        b3 = PQ[d.LQ[2].offB];
+    };
+
+    STAMP(0, 0);
+    if (has_pi) {
+        // ---- policy on this block's rows ----
+        rows.issue(d.KP, obs, O, O, nullptr, 0, 0);
+        r0.init(PP + d.LP[0].offW, d.LP[0].Kp, 64 * wave, 16);
+        r0.fill(d.KP >> 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv0[t] = PP[d.LP[0].offB + 64 * wave + 16 * t + c];
+        SB();
+        r1.init(PP + d.LP[1].offW, H, 64 * wave, 16);
+        r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+        r1.fill(H >> 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv1[t] = PP[d.LP[1].offB + 64 * wave + 16 * t + c];
+        rh.init(PP + d.LP[2].offW, H, 0, 16, 4 * wave);    // head: contraction split over the waves
+        SB();
+        rows.commit(XP, KLP, d.KP);
+        __syncthreads();
+        STAMP(0, 1);
+        {
+            f32x4 acc[4] = {};
+            gemm_ring(r0, XP, KLP, d.KP >> 4, acc);
+            rh.fill(4);
+            hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (pass == 2) ? d.PH1T : nullptr, B, row0);
+            issue_q_first();               // r0 / rows / bv0 are free again: start the Q net's stream
+            SB();
         }
-    } else if (!next) {
-        d.anew[grow * 16 + a] = 0.f;
-    } else {
-        d.a2[grow * 16 + a] = 0.f;
-    }
-    const float lsum = group16_sum(lp);
-    if (a == 0) (next ? d.logpi2 : d.logpi)[grow] = lsum;
-    if (!next) {
-        // block partial of sum(log_pi) in a fixed order (deterministic alpha)
         __syncthreads();
-        if (a == 0) red[row] = lsum;
+        STAMP(0, 2);
+        {
+            f32x4 acc[4] = {};
+            gemm_ring(r1, X1, H, H >> 4, acc);
+            STAMP(0, 3);
+            hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, (pass == 2) ? d.PH2T : nullptr, B, row0);
+            issue_q_second();
+            SB();
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        {
+            f32x4 acc[NTH] = {};
+            gemm_ring(rh, X2, H, 4, acc, 4 * wave);
+            splitk_reduce<NTH>(acc, PP + d.LP[2].offB, red, HD, 32);
+        }
+        rows.commit(XQ, KLQ, d.KQ, O, O + A);   // obs part + zero padding; the head below writes the action columns
+        // tanh-Gaussian head: thread = (row, a)
+        const int a = part, grow = row0 + row;
+        float lp = 0.f;
+        if (a < A) {
+            const float mean = HD[row * 32 + a];
+            const float raw = HD[row * 32 + A + a];
+            const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+            const float stdv = expf(lstd);
+            const float *epp = next ? d.eps2 : d.eps1;
+            const float eps = epp ? epp[grow * A + a]
+                                  : philox_normal(d.noise_seed, (unsigned long long)(step_base + j),
+                                                  (unsigned)(grow * 16 + a), next ? 1u : 0u);
+            const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
+            const float act = tanhf(zz);
+            const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
+            const float var = __fmul_rn(stdv, stdv);
+            const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+            lp = nlp - logf(1.0f - act * act + TANH_EPS);
+            XQ[lds_off(row, O + a, KLQ)] = act;
+            if (pass == 2) {
+                d.mu[grow * 16 + a] = mean;
+                d.ls[grow * 16 + a] = lstd;
+                d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
+                d.z[grow * 16 + a] = zz;
+                d.anew[grow * 16 + a] = act;
+                d.epsv[grow * 16 + a] = eps;
+            } else if (pass == 4) {
+                d.a2[grow * 16 + a] = act;
+            }
+        } else if (pass == 2) {
+            d.anew[grow * 16 + a] = 0.f;
+        } else if (pass == 4) {
+            d.a2[grow * 16 + a] = 0.f;
+        }
+        const float lsum = group16_sum(lp);
+        if (owner && a == 0) (next ? d.logpi2 : d.logpi)[grow] = lsum;
+        if (pass == 2 && a == 0) red[row] = lsum;
+        __syncthreads();
+        if (pass == 2 && threadIdx.x == 0) {
+            // block partial of sum(log_pi) in a fixed order, then the arrival ticket
             float s = 0.f;
             for (int i = 0; i < RB; ++i) s += red[i];
-            d.part_logpi[rb] = s;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: six Q forward passes.  pass = blockIdx / NB:
-//   0 Q1(s,a) 1 Q2(s,a) 2 Q1(s,a_new) 3 Q2(s,a_new) 4 T1(s',a') 5 T2(s',a')
-// The extra last block performs the alpha Adam step (SURVEY Appendix A lines 4-6) and publishes
-// this step's Adam bias corrections for K5.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int B = d.B, O = d.O, A = d.A;
-    if (blockIdx.x == (unsigned)(6 * d.NB)) {
-        if (threadIdx.x == 0) {
-            Ctl *c = d.ctl;
-            const double tt = (double)(c->adam_base + j + 1);
-            const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
-            c->bc1 = bc1;
-            c->bc2s = sqrt(bc2);
-            if (d.auto_alpha) {
-                float s = 0.f;
-                for (int i = 0; i < d.NB; ++i) s += d.part_logpi[i];
-                const float mean_lp = s / (float)B + d.target_entropy;      // mean(log_pi + H)
-                const float la = c->log_alpha;
-                // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0, so log_alpha == 0 logs -0.0
-                c->alpha_loss = -((la * mean_lp) + 0.0f);
-                const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
-                const float m = c->a_m + (1.0f - ADAM_B1) * (gr - c->a_m);
-                const float v = c->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
-                const float step_size = (float)((double)d.alpha_lr / bc1);
-                const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
-                const float nla = la + (-step_size * m) / denom;
-                c->a_m = m; c->a_v = v; c->log_alpha = nla;
-                c->alpha = expf(nla);
-            } else {
-                c->alpha = 1.0f;
-                c->alpha_loss = 0.0f;
+            __hip_atomic_store(&d.part_logpi[rb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            Ctl *cc = d.ctl;
+            const unsigned tk = __hip_atomic_fetch_add(&cc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == (unsigned)(d.NB - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                cc->ticket = 0u;
+                const double tt = (double)(cc->adam_base + j + 1);
+                const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
+                cc->bc1 = bc1;
+                cc->bc2s = sqrt(bc2);
+                if (d.auto_alpha) {
+                    float sum = 0.f;
+                    for (int i = 0; i < d.NB; ++i)
+                        sum += __hip_atomic_load(&d.part_logpi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const float mean_lp = sum / (float)B + d.target_entropy;     // mean(log_pi + H)
+                    const float la = cc->log_alpha;
+                    // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0 => log_alpha == 0 logs -0.0
+                    cc->alpha_loss = -((la * mean_lp) + 0.0f);
+                    const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
+                    const float m = cc->a_m + (1.0f - ADAM_B1) * (gr - cc->a_m);
+                    const float v = cc->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
+                    const float step_size = (float)((double)d.alpha_lr / bc1);
+                    const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
+                    const float nla = la + (-step_size * m) / denom;
+                    cc->a_m = m; cc->a_v = v; cc->log_alpha = nla;
+                    cc->alpha = expf(nla);
+                } else {
+                    cc->alpha = 1.0f;
+                    cc->alpha_loss = 0.0f;
+                }
             }
         }
-        return;
+    } else {
+        issue_q_first();
+        SB();
+        issue_q_second();
+        SB();
+        rows.commit(XQ, KLQ, d.KQ);
+        __syncthreads();
     }
-    const int KL0 = (d.KQ + 63) & ~63;
-    float *X0 = lds;
-    float *X1 = X0 + RB * KL0;
-    float *X2 = X1 + RB * H;
-    const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
-    const int row0 = rb * RB;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
-    const int net = (pass < 4) ? 1 + (pass & 1) : 3 + (pass & 1);
-    const float *P = d.P[net];
 
-    WRing<4> r0;
-    WRing<4, RDH4> r1;
-    RowRegs rows;
-    const float *obs = S + ((pass >= 4) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
-    const float *act;
-    int lda;
-    if (pass < 2) { act = S + SL.off_act + (size_t)row0 * A; lda = A; }
-    else if (pass < 4) { act = d.anew + (size_t)row0 * 16; lda = 16; }
-    else { act = d.a2 + (size_t)row0 * 16; lda = 16; }
-    rows.issue(d.KQ, obs, O, O, act, A, lda);
-    r0.init(P + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
-    r0.fill(d.KQ >> 4);
-    float bv0[4], bv1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) bv0[t] = P[d.LQ[0].offB + 64 * wave + 16 * t + c];
-    SB();
-    r1.init(P + d.LQ[1].offW, H, 64 * wave, 16);
-    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
-    r1.fill(H >> 4);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) bv1[t] = P[d.LQ[1].offB + 64 * wave + 16 * t + c];
-    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
-    float w3[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) w3[u] = P[d.LQ[2].offW + part + 16 * u];
-    const float b3 = P[d.LQ[2].offB];
-    SB();
-    rows.commit(X0, KL0, d.KQ);
-    __syncthreads();
+    // ---- Q / target-Q net on cat(obs, action) ----
+    STAMP(0, 4);
     float *h1T = (pass < 4) ? d.QH1T + (size_t)pass * H * B : nullptr;
     float *h2T = (pass < 4) ? d.QH2T + (size_t)pass * H * B : nullptr;
     {
         f32x4 acc[4] = {};
-        gemm_ring(r0, X0, KL0, d.KQ >> 4, acc);
+        gemm_ring(r0, XQ, KLQ, d.KQ >> 4, acc);
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, h1T, B, row0);
     }
     __syncthreads();
+    STAMP(0, 5);
     {
         f32x4 acc[4] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
+        STAMP(0, 6);
         hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, h2T, B, row0);
     }
     __syncthreads();
@@ -515,6 +512,7 @@ __global__ __launch_bounds__(256) void k_q_fwd(Dev d, const float *__restrict__ 
     for (int u = 0; u < 16; ++u) s += X2[lds_off(row, part + 16 * u, H)] * w3[u];
     s = group16_sum(s);
     if (part == 0) d.q[(size_t)pass * B + row0 + row] = s + b3;
+    STAMP(0, 7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1056,18 +1054,16 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     hipStream_t s = t->stream;
     const int NB = t->NB;
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_fwd<1>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
-    else hipLaunchKernelGGL(k_policy_fwd<2>, dim3(2 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
+    if (t->NH == 16) hipLaunchKernelGGL(k_fwd<1>, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
+    else hipLaunchKernelGGL(k_fwd<2>, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k_q_fwd, dim3(6 * NB + 1), dim3(256), t->lds_qf, s, d, S, SL, j);
-    if (ev) SAC_HIP(hipEventRecord(ev[2], s));
     hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, S, SL, j);
-    if (ev) SAC_HIP(hipEventRecord(ev[3], s));
+    if (ev) SAC_HIP(hipEventRecord(ev[2], s));
     if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
     else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
-    if (ev) SAC_HIP(hipEventRecord(ev[4], s));
+    if (ev) SAC_HIP(hipEventRecord(ev[3], s));
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, j);
-    if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
+    if (ev) { SAC_HIP(hipEventRecord(ev[4], s)); SAC_HIP(hipEventRecord(ev[5], s)); }
     SAC_HIP(hipGetLastError());
     return 0;
 }
@@ -1198,12 +1194,17 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
 
     const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
-    t->lds_pf = sizeof(float) * (size_t)(RB * KL0p + 2 * RB * H + RB * 32 + 4 * nth * 256);
-    t->lds_qf = sizeof(float) * (size_t)(RB * KL0q + 2 * RB * H);
+    t->lds_pf = sizeof(float) * (size_t)(RB * KL0p + RB * KL0q + 2 * RB * H + RB * 32 + 4 * nth * 256);
+    t->lds_qf = 0;
     t->lds_qb = sizeof(float) * (size_t)(2 * RB * H + 1024);
     t->lds_pb = sizeof(float) * (size_t)(RB * 64 + RB * H);
-    SAC_REQUIRE(t->lds_pf <= 64 * 1024 && t->lds_qf <= 64 * 1024,
-                "observation too wide for the 64 KB LDS row-block budget (obs_dim=%d)", t->O);
+    SAC_REQUIRE(t->lds_pf <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
+    if (t->lds_pf > 64 * 1024) {
+        if (nth == 1) SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd<1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
+        else SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
+    }
     SAC_HIP(hipStreamSynchronize(s));
     *out = t;
     return 0;
@@ -1404,31 +1405,33 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     t->dev.eps1 = t->dev.eps2 = nullptr;
     if (stage_batches(t, b, n_steps)) return -1;
     if (begin_loop(t)) return -1;
-    std::vector<hipEvent_t> ev((size_t)n_steps * 7);
+    constexpr int NE = 6;            // e0 K1 e1 K2 e2 K3 e3 K4 e4 (nothing) e5
+    std::vector<hipEvent_t> ev((size_t)n_steps * NE);
     for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
     for (int64_t i = 0; i < n_steps; ++i)
-        if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * 7])) return -1;
+        if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * NE])) return -1;
     if (advance(t, (int)n_steps)) return -1;
     SAC_HIP(hipStreamSynchronize(s));
-    // interval k = launch k between two event records; the empty interval ev[5]->ev[6] measures what
-    // an event pair costs by itself and is subtracted
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    // interval k = launch k between two event records; the empty interval e4->e5 measures what an
+    // event pair costs by itself and is subtracted from the four kernel intervals
+    double acc[NE - 1] = {0, 0, 0, 0, 0};
     for (int64_t i = 0; i < n_steps; ++i)
-        for (int k = 0; k < 6; ++k) {
+        for (int k = 0; k < NE - 1; ++k) {
             float ms = 0.f;
-            SAC_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * 7 + k], ev[(size_t)i * 7 + k + 1]));
+            SAC_HIP(hipEventElapsedTime(&ms, ev[(size_t)i * NE + k], ev[(size_t)i * NE + k + 1]));
             acc[k] += ms;
         }
     float tot = 0.f;
-    SAC_HIP(hipEventElapsedTime(&tot, ev[0], ev[(size_t)n_steps * 7 - 1]));
+    SAC_HIP(hipEventElapsedTime(&tot, ev[0], ev[(size_t)n_steps * NE - 1]));
     for (auto &e : ev) (void)hipEventDestroy(e);
     SAC_HIP(hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
     SAC_HIP(hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
-    const double empty = acc[5] / (double)n_steps;
-    for (int k = 0; k < 5; ++k) {
+    const double empty = acc[NE - 2] / (double)n_steps;
+    for (int k = 0; k < 4; ++k) {
         const double v = acc[k] / (double)n_steps - empty;
         out_ms[2 + k] = (float)(v > 0 ? v : 0);
     }
+    out_ms[6] = (float)empty;
     out_ms[7] = tot;
     t->mirror_valid = false;
     return 0;

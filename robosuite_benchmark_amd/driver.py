@@ -1,0 +1,186 @@
+"""Own counterpart of the reference's experiment assembly + epoch loop for boxes without
+rlkit / robosuite (the GPU box): variant.json -> nets, trainer, HBM replay buffer -> epochs.
+
+Mirrors /root/reference/util/rlkit_utils.py:31-165 (``experiment``) and
+/root/reference/util/rlkit_custom.py:199-301 (``_train`` / ``_log_stats``): prefill, then per
+epoch {eval collection, exploration collection, add_paths, num_trains_per_train_loop x
+(random_batch; train), end_epoch + one progress.csv row with the reference's column names}.
+Environment stepping stays on the host; with no robosuite here the env is a synthetic stand-in
+with the task's observation/action sizes (SURVEY.md section 8d synthetic data)."""
+from __future__ import annotations
+
+import csv
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from .networks import FlattenMlp, MakeDeterministic, TanhGaussianPolicy
+from .replay_buffer import EnvReplayBuffer
+from .sac import SACTrainer
+from .variant import env_dims, validate
+
+
+class SyntheticEnv:
+    """Host-side stand-in for NormalizedBoxEnv(GymWrapper(robosuite env)): shaped reward in [0,1],
+    never terminates (ignore_done=True in every shipped variant)."""
+
+    def __init__(self, obs_dim, action_dim, horizon=500, seed=0):
+        self.obs_dim, self.action_dim, self.horizon = obs_dim, action_dim, horizon
+        self._rs = np.random.RandomState(seed)
+        self._goal = self._rs.normal(0, 0.5, action_dim)
+        self._t = 0
+
+    def reset(self):
+        self._t = 0
+        self._obs = self._rs.normal(0, 0.5, self.obs_dim)
+        return self._obs
+
+    def step(self, action):
+        self._t += 1
+        rew = float(np.exp(-np.sum((np.asarray(action) - np.tanh(self._goal)) ** 2)))
+        self._obs = 0.9 * self._obs + self._rs.normal(0, 0.2, self.obs_dim)
+        return self._obs, rew, False, {}
+
+
+def rollout(env, policy, max_path_length):
+    """rlkit rollout contract (rlkit_custom.py:487-495 path dict)."""
+    obs_l, act_l, rew_l, nobs_l, term_l = [], [], [], [], []
+    o = env.reset()
+    policy.reset()
+    for _ in range(max_path_length):
+        a, _ = policy.get_action(o)
+        no, r, d, _ = env.step(a)
+        obs_l.append(o); act_l.append(a); rew_l.append(r); nobs_l.append(no); term_l.append(d)
+        o = no
+        if d:
+            break
+    n = len(obs_l)
+    return dict(observations=np.array(obs_l), actions=np.array(act_l), rewards=np.array(rew_l).reshape(n, 1),
+                next_observations=np.array(nobs_l), terminals=np.array(term_l).reshape(n, 1),
+                agent_infos=[{}] * n, env_infos=[{}] * n)
+
+
+class PathCollector:
+    """MdpPathCollector.collect_new_paths: the last path is clipped to the remaining step budget and
+    kept unless discard_incomplete_paths (pins 'exploration/num paths total' = 12 at epoch 0)."""
+
+    def __init__(self, env, policy):
+        self.env, self.policy = env, policy
+        self.num_steps_total, self.num_paths_total, self.epoch_paths = 0, 0, []
+
+    def collect_new_paths(self, max_path_length, num_steps, discard_incomplete_paths):
+        paths, collected = [], 0
+        while collected < num_steps:
+            mpl = min(max_path_length, num_steps - collected)
+            path = rollout(self.env, self.policy, mpl)
+            plen = len(path["actions"])
+            if plen != max_path_length and not path["terminals"][-1] and discard_incomplete_paths:
+                break
+            collected += plen
+            paths.append(path)
+        self.num_paths_total += len(paths)
+        self.num_steps_total += collected
+        self.epoch_paths.extend(paths)
+        return paths
+
+    def end_epoch(self, epoch):
+        self.epoch_paths = []
+
+    def get_diagnostics(self):
+        return OrderedDict([("num steps total", self.num_steps_total), ("num paths total", self.num_paths_total)])
+
+
+def _stats(name, x):
+    x = np.asarray(x, dtype=np.float64).ravel()
+    return OrderedDict([(name + " Mean", float(np.mean(x))), (name + " Std", float(np.std(x))),
+                        (name + " Max", float(np.max(x))), (name + " Min", float(np.min(x)))])
+
+
+def path_information(paths, prefix, expl_len=None):
+    d = OrderedDict()
+    d.update(_stats(prefix + "path length", [len(p["actions"]) for p in paths]))
+    d.update(_stats(prefix + "Rewards", np.vstack([p["rewards"] for p in paths])))
+    d.update(_stats(prefix + "Returns", [np.sum(p["rewards"]) for p in paths]))
+    if expl_len is not None:      # evaluation/ExplReturns: return truncated at the exploration horizon
+        d.update(_stats(prefix + "ExplReturns", [np.sum(p["rewards"][:expl_len]) for p in paths]))
+    d.update(_stats(prefix + "Actions", np.vstack([p["actions"] for p in paths])))
+    d[prefix + "Num Paths"] = len(paths)
+    d[prefix + "Average Returns"] = float(np.mean([np.sum(p["rewards"]) for p in paths]))
+    return d
+
+
+def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num_epochs=None, device=0,
+               fused_loop=True, quiet=False):
+    """variant.json -> training run.  Returns the list of progress rows (also written to
+    <log_dir>/progress.csv when log_dir is given)."""
+    validate(variant)
+    np.random.seed(seed)                                          # scripts/train.py:112 (args.seed, not variant seed)
+    O, A = env_dims(variant["expl_environment_kwargs"], obs_dim, action_dim)
+    ak, tk = variant["algorithm_kwargs"], variant["trainer_kwargs"]
+    expl_env = SyntheticEnv(O, A, variant["expl_environment_kwargs"].get("horizon", 500), seed)
+    eval_env = SyntheticEnv(O, A, variant["eval_environment_kwargs"].get("horizon", 500), seed + 1)
+    qf1, qf2, tqf1, tqf2 = (FlattenMlp(input_size=O + A, output_size=1, **variant["qf_kwargs"]) for _ in range(4))
+    policy = TanhGaussianPolicy(obs_dim=O, action_dim=A, **variant["policy_kwargs"])
+    eval_policy = MakeDeterministic(policy)
+    trainer = SACTrainer(env=eval_env, policy=policy, qf1=qf1, qf2=qf2, target_qf1=tqf1, target_qf2=tqf2,
+                         batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
+    buf = EnvReplayBuffer(variant["replay_buffer_size"], obs_dim=O, action_dim=A, device=device)
+    expl, evalc = PathCollector(expl_env, policy), PathCollector(eval_env, eval_policy)
+    rows, t_start = [], time.time()
+    writer, fh = None, None
+    if ak.get("min_num_steps_before_training", 0) > 0:
+        buf.add_paths(expl.collect_new_paths(ak["expl_max_path_length"], ak["min_num_steps_before_training"], False))
+        expl.end_epoch(-1)
+    for epoch in range(num_epochs if num_epochs is not None else ak["num_epochs"]):
+        t0 = time.time()
+        evalc.collect_new_paths(ak["eval_max_path_length"], ak["num_eval_steps_per_epoch"], True)
+        t1 = time.time()
+        new_paths = expl.collect_new_paths(ak["expl_max_path_length"], ak["num_expl_steps_per_train_loop"], False)
+        t2 = time.time()
+        buf.add_paths(new_paths)
+        t3 = time.time()
+        buf.seed_from_numpy()                                     # continue the np.random global stream ...
+        n_train = ak["num_trains_per_train_loop"]
+        if fused_loop:
+            trainer.train_loop(buf, n_train, batch_size=ak["batch_size"])
+        else:
+            for _ in range(n_train):
+                trainer.train(buf.random_batch(ak["batch_size"]))
+        buf.sync_to_numpy()                                       # ... and hand it back to the host
+        t4 = time.time()
+        row = OrderedDict()
+        row.update(("replay_buffer/" + k, v) for k, v in buf.get_diagnostics().items())
+        row.update(("trainer/" + k, v) for k, v in trainer.get_diagnostics().items())
+        row.update(("exploration/" + k, v) for k, v in expl.get_diagnostics().items())
+        row.update(path_information(expl.epoch_paths, "exploration/"))
+        row.update(("evaluation/" + k, v) for k, v in evalc.get_diagnostics().items())
+        row.update(path_information(evalc.epoch_paths, "evaluation/", ak["expl_max_path_length"]))
+        trainer.end_epoch(epoch); buf.end_epoch(epoch); expl.end_epoch(epoch); evalc.end_epoch(epoch)
+        t5 = time.time()
+        row["time/data storing (s)"] = t3 - t2
+        row["time/evaluation sampling (s)"] = t1 - t0
+        row["time/exploration sampling (s)"] = t2 - t1
+        row["time/logging (s)"] = t5 - t4
+        row["time/saving (s)"] = 0.0
+        row["time/training (s)"] = t4 - t3
+        row["time/epoch (s)"] = t5 - t0
+        row["time/total (s)"] = t5 - t_start
+        row["Epoch"] = epoch
+        rows.append(row)
+        if log_dir is not None:
+            if writer is None:
+                os.makedirs(log_dir, exist_ok=True)
+                fh = open(os.path.join(log_dir, "progress.csv"), "w", newline="")
+                writer = csv.DictWriter(fh, fieldnames=list(row.keys()))
+                writer.writeheader()
+            writer.writerow(row)
+            fh.flush()
+        if not quiet:
+            print(f"epoch {epoch}: buffer {row['replay_buffer/size']}  QF1 {row['trainer/QF1 Loss']:.4f}  "
+                  f"alpha {row['trainer/Alpha']:.4f}  training {row['time/training (s)']:.3f}s "
+                  f"({n_train / max(row['time/training (s)'], 1e-9):.0f} steps/s)", flush=True)
+    if fh:
+        fh.close()
+    return rows

@@ -1,0 +1,66 @@
+"""variant.json handling (mirror of the schema scripts/train.py builds and consumes).
+
+Reference: /root/reference/scripts/train.py:53-96 (variant dict / --variant JSON),
+/root/reference/util/arguments.py:87-202 (defaults), /root/reference/util/rlkit_utils.py:39-62
+(env construction -> obs_dim / action_dim).  robosuite is not installed where this library runs, so
+the (obs_dim, action_dim) the reference reads off the env come from a table pinned by the fc0 /
+last_fc shapes inside the shipped params.pkl files (dims table)."""
+from __future__ import annotations
+
+import json
+
+# (env_name, n_robots) -> obs_dim for OSC_POSE-family runs with use_object_obs=True, no cameras
+OBS_DIMS = {
+    ("Lift", 1): 42, ("Door", 1): 46, ("PickPlaceCan", 1): 46, ("PickPlaceMilk", 1): 46,
+    ("NutAssemblyRound", 1): 46, ("Stack", 1): 55, ("Wipe", 1): 379,
+    ("TwoArmPegInHole", 2): 73, ("TwoArmHandoff", 2): 86, ("TwoArmLift", 2): 89,
+}
+# controller -> action dims per arm (gripper included); Wipe has no gripper (one fewer)
+ACT_PER_ARM = {"OSC_POSE": 7, "OSC_POSITION": 4, "JOINT_VELOCITY": 8, "JOINT_TORQUE": 8, "JOINT_POSITION": 8,
+               "IK_POSE": 7}
+
+
+def load_variant(path):
+    with open(path) as f:
+        return json.load(f)
+
+
+def default_variant(env="Lift", robots=("Panda",), controller="OSC_POSE", seed=1, batch_size=256,
+                    target_update_period=1):
+    """The dict scripts/train.py:53-77 builds from the argparse defaults (arguments.py)."""
+    envkw = dict(env_name=env, robots=list(robots), horizon=500, control_freq=20, controller=controller,
+                 reward_scale=1.0, hard_reset=False, ignore_done=True)
+    return dict(
+        algorithm="SAC", seed=seed, version="normal", replay_buffer_size=int(1e6),
+        qf_kwargs=dict(hidden_sizes=[256, 256]), policy_kwargs=dict(hidden_sizes=[256, 256]),
+        algorithm_kwargs=dict(num_epochs=2000, num_eval_steps_per_epoch=2500, num_trains_per_train_loop=1000,
+                              num_expl_steps_per_train_loop=2500, min_num_steps_before_training=3300,
+                              expl_max_path_length=500, eval_max_path_length=500, batch_size=batch_size),
+        trainer_kwargs=dict(discount=0.99, soft_target_tau=5e-3, target_update_period=target_update_period,
+                            policy_lr=1e-3, qf_lr=5e-4, reward_scale=1.0, use_automatic_entropy_tuning=True),
+        expl_environment_kwargs=dict(envkw), eval_environment_kwargs=dict(envkw))
+
+
+def env_dims(env_kwargs, obs_dim=None, action_dim=None):
+    """(obs_dim, action_dim) the reference would read from the robosuite env (rlkit_utils.py:61-62)."""
+    if obs_dim is not None and action_dim is not None:
+        return int(obs_dim), int(action_dim)
+    name, robots = env_kwargs["env_name"], env_kwargs["robots"]
+    robots = [robots] if isinstance(robots, str) else list(robots)
+    ctrl = env_kwargs.get("controller", "OSC_POSE")
+    key = (name, len(robots))
+    if key not in OBS_DIMS or ctrl not in ACT_PER_ARM:
+        raise KeyError(f"no pinned dims for env {name!r} x{len(robots)} / controller {ctrl!r}: pass obs_dim/action_dim")
+    per_arm = ACT_PER_ARM[ctrl] - (1 if name == "Wipe" else 0)
+    return OBS_DIMS[key], per_arm * len(robots)
+
+
+def validate(variant):
+    """The checks the reference does implicitly (KeyError / assert at rlkit_utils.py:34)."""
+    if variant.get("algorithm", "SAC") != "SAC":
+        raise ValueError(f"agent {variant.get('algorithm')!r}: only SAC is on the MI355X hot path (TD3 is out of scope)")
+    for k in ("replay_buffer_size", "qf_kwargs", "policy_kwargs", "algorithm_kwargs", "trainer_kwargs",
+              "expl_environment_kwargs", "eval_environment_kwargs"):
+        if k not in variant:
+            raise KeyError(f"variant is missing {k!r}")
+    return variant

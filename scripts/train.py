@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's scripts/train.py for the MI355X path:
+    python scripts/train.py --variant <variant.json> --seed S --log_dir DIR [--epochs N]
+Runs the variant unchanged (batch size, lrs, tau, period, buffer size ... from the JSON) on the
+HIP library with a synthetic environment of the task's dimensions (robosuite is not installed)."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from robosuite_benchmark_amd.driver import experiment  # noqa: E402
+from robosuite_benchmark_amd.variant import default_variant, load_variant  # noqa: E402
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variant", type=str, default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--log_dir", type=str, default=None)
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--env", type=str, default="Lift")
+    ap.add_argument("--batch_size", type=int, default=256)
+    args = ap.parse_args()
+    variant = load_variant(args.variant) if args.variant else default_variant(env=args.env, seed=args.seed,
+                                                                              batch_size=args.batch_size)
+    experiment(variant, log_dir=args.log_dir, seed=args.seed, num_epochs=args.epochs)
