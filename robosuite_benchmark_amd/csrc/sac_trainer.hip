@@ -42,10 +42,17 @@ constexpr int RD = 4;             // ring depth (k-chunks in flight) for the run
 constexpr int RDH4 = SAC_RDH;     // hidden layers' ring depth (measured: 4 > 16; the weight stream is bound by the
                                   // per-CU fill rate from the Infinity Cache, not by exposed latency)
 
-struct Ctl {                       // device-resident step state
-    long long step_base;           // rlkit _n_train_steps_total at the start of the current chunk
-    long long adam_base;           // optimizer step count at the start of the current chunk
-    int loop_base;                 // steps of the current sac_train_loop already finished
+// Step counters are HOST state passed as launch arguments (a device-side counter would put a
+// dependent, wave-uniform load -- readfirstlane + vmcnt(0) -- in front of every kernel's first
+// data access); only what the device itself produces lives here.
+struct StepArg {
+    long long step_now;            // rlkit _n_train_steps_total of this step (pre-increment)
+    long long adam_t;              // optimizer step count of this step (1-based)
+    int loop_pos;                  // index of this step inside the current sac_train_loop
+    int pad;
+};
+
+struct Ctl {                       // device-resident state: entropy coefficient + this step's Adam scalars
     float log_alpha, a_m, a_v, alpha, alpha_loss;
     unsigned ticket;               // arrival counter of the forward kernel's owner blocks
     int pad[1];
@@ -98,7 +105,7 @@ struct DwLayer {
     float lr;
 };
 constexpr int NDW = 9;
-struct DwTable { DwLayer L[NDW]; int njobs; };
+struct DwTable { const DwLayer *L; int job0[NDW]; int njobs; };   // L: device array, read with scalar loads
 
 // ------------------------------------------------------------------------------------------
 // in-kernel stamps (diagnostic build only, -DSAC_STAMPS; the shipped library has none)
@@ -127,6 +134,26 @@ __device__ __forceinline__ int lds_off(int row, int k, int KL) {
 // hipcc sinks prefetch loads down to their first use (and hoists bulk loads above small critical
 // ones); vmcnt completes in issue order, so the ISSUE ORDER is part of the design.  SB pins it.
 #define SB() __builtin_amdgcn_sched_barrier(0)
+// IR-level code motion hoists pure arithmetic (expf, fminf ...) up to right behind the load that
+// feeds it -- across sched_barrier -- which puts an s_waitcnt in the middle of the prologue's load
+// burst.  USE_FROM_HERE(x) makes x opaque at this point, so nothing computed from it can move above.
+#define USE_FROM_HERE(x) asm volatile("" : "+v"(x))
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() also carries a workgroup-scope fence
+// for global memory, which hipcc lowers to s_waitcnt vmcnt(0): vmcnt counts loads AND stores in
+// issue order, so every barrier would drain the weight stream and the prefetches in flight (a full
+// L2 / Infinity-Cache round trip per barrier).  The step kernels exchange data between waves only
+// through LDS (and through explicit agent-scope release/acquire where global memory is involved),
+// so their barriers wait for this wave's LDS operations only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Wave-uniform device scalars (alpha, Adam bias corrections): read through the scalar cache
+// (s_load, waited for at first use).  A plain load of a uniform address becomes a vector load +
+// v_readfirstlane with an immediate vmcnt(0), i.e. a serial round trip in front of the prologue's
+// loads.  The scalar cache is invalidated at kernel start, and these words are only ever written
+// by an EARLIER kernel of the stream.
+template <typename T>
+__device__ __forceinline__ T sload(const T *p) {
+    return *(const __attribute__((address_space(4))) T *)(uintptr_t)p;
+}
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
@@ -203,6 +230,30 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
     }
 }
 
+// First layers (K = obs or obs+act, a few k-chunks): every chunk was requested by fill(), nothing is
+// refilled, and the loop is straight-line code -- hipcc's s_waitcnt insertion counts loads exactly
+// only when no loop back-edge separates a load from its use (with a runtime trip count it falls
+// back to vmcnt(0), which would drain the NEXT layer's 64 KB prefetch before this GEMM starts).
+template <int NT, int D>
+__device__ __forceinline__ void gemm_straight(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const float *xrow = X + r * KL;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        if (u < KS) {
+            const f32x4 a = ld4(xrow + 4 * ((4 * u + g) ^ r));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], R.b[u][t][i], acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+constexpr int RD0 = 8;            // narrow first layers: up to 8 k-chunks (K <= 128) held at once
+
 // split-K epilogue: the four waves each hold a partial [16 x 16*NTT]; sum them through LDS into
 // `out` (row-major [16][ldo]) + bias.  red = 4*NTT*256 floats.
 template <int NTT>
@@ -211,7 +262,7 @@ __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const flo
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int t = 0; t < NTT; ++t) st4(red + ((wave * NTT + t) * 64 + lane) * 4, acc[t]);
-    __syncthreads();
+    lds_barrier();
     for (int e = threadIdx.x; e < NTT * 256; e += 256) {
         const int t = e >> 8, l = (e >> 2) & 63, i = e & 3;
         float s = 0.f;
@@ -220,7 +271,7 @@ __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const flo
         const int row = 4 * (l >> 4) + i, col = 16 * t + (l & 15);
         out[row * ldo + col] = s + (bias ? bias[col] : 0.f);
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -252,7 +303,7 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 
 // swizzled LDS row-block [16][KL] from row-major global rows (two sources concatenated), in two
 // phases: issue() puts the loads in flight early, commit() writes LDS once they are needed.
-constexpr int ROWS_MAXE = 32;                 // Kfill <= 512
+template <int ROWS_MAXE>                      // Kfill <= 16 * ROWS_MAXE
 struct RowRegs {
     float v[ROWS_MAXE];
     __device__ __forceinline__ void issue(int Kfill, const float *__restrict__ s0, int n0, int ld0,
@@ -315,8 +366,8 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 // reduces sum(log_pi) in a fixed order and performs the alpha Adam step (SURVEY Appendix A
 // lines 4-6); it also publishes this step's Adam bias corrections for the weight-gradient kernel.
 // ------------------------------------------------------------------------------------------
-template <int NTH>
-__global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
+template <int NTH, bool WIDE>
+__global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A;
     const int KLP = (d.KP + 63) & ~63, KLQ = (d.KQ + 63) & ~63;
@@ -334,13 +385,16 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
     const float *PP = d.P[0];
     const float *PQ = d.P[(pass < 4) ? 1 + (pass & 1) : 3 + (pass & 1)];
     const float *obs = S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
-    const long long step_base = d.ctl->step_base;          // used only by the noise counter, much later
 
-    WRing<4> r0;
+    WRing<4, WIDE ? RD : RD0> r0;          // WIDE: obs+act > 128 (Wipe): generic ring loop
     WRing<4, RDH4> r1;
     WRing<NTH> rh;
-    RowRegs rows;
+    RowRegs<WIDE ? 32 : 8> rows;
     float bv0[4], bv1[4], w3[16], b3 = 0.f;
+    auto gemm_first = [&](const float *X, int KL, int KS, f32x4 (&acc)[4]) {
+        if constexpr (WIDE) gemm_ring(r0, X, KL, KS, acc);
+        else gemm_straight(r0, X, KL, KS, acc);
+    };
     auto issue_q_first = [&]() {       // Q net: input rows, first layer, its bias
         rows.issue(d.KQ, obs, O, O, S + SL.off_act + (size_t)row0 * A, (pass < 2) ? A : 0, A);
         r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
@@ -376,17 +430,17 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         rh.init(PP + d.LP[2].offW, H, 0, 16, 4 * wave);    // head: contraction split over the waves
         SB();
         rows.commit(XP, KLP, d.KP);
-        __syncthreads();
+        lds_barrier();
         STAMP(0, 1);
         {
             f32x4 acc[4] = {};
-            gemm_ring(r0, XP, KLP, d.KP >> 4, acc);
+            gemm_first(XP, KLP, d.KP >> 4, acc);
             rh.fill(4);
             hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (pass == 2) ? d.PH1T : nullptr, B, row0);
             issue_q_first();               // r0 / rows / bv0 are free again: start the Q net's stream
             SB();
         }
-        __syncthreads();
+        lds_barrier();
         STAMP(0, 2);
         {
             f32x4 acc[4] = {};
@@ -396,7 +450,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
             issue_q_second();
             SB();
         }
-        __syncthreads();
+        lds_barrier();
         {
             f32x4 acc[NTH] = {};
             gemm_ring(rh, X2, H, 4, acc, 4 * wave);
@@ -413,7 +467,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
             const float stdv = expf(lstd);
             const float *epp = next ? d.eps2 : d.eps1;
             const float eps = epp ? epp[grow * A + a]
-                                  : philox_normal(d.noise_seed, (unsigned long long)(step_base + j),
+                                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now,
                                                   (unsigned)(grow * 16 + a), next ? 1u : 0u);
             const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
             const float act = tanhf(zz);
@@ -440,7 +494,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         const float lsum = group16_sum(lp);
         if (owner && a == 0) (next ? d.logpi2 : d.logpi)[grow] = lsum;
         if (pass == 2 && a == 0) red[row] = lsum;
-        __syncthreads();
+        lds_barrier();
         if (pass == 2 && threadIdx.x == 0) {
             // block partial of sum(log_pi) in a fixed order, then the arrival ticket
             float s = 0.f;
@@ -453,7 +507,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
             if (tk == (unsigned)(d.NB - 1)) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 cc->ticket = 0u;
-                const double tt = (double)(cc->adam_base + j + 1);
+                const double tt = (double)sa.adam_t;
                 const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
                 cc->bc1 = bc1;
                 cc->bc2s = sqrt(bc2);
@@ -485,7 +539,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         issue_q_second();
         SB();
         rows.commit(XQ, KLQ, d.KQ);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- Q / target-Q net on cat(obs, action) ----
@@ -494,10 +548,10 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
     float *h2T = (pass < 4) ? d.QH2T + (size_t)pass * H * B : nullptr;
     {
         f32x4 acc[4] = {};
-        gemm_ring(r0, XQ, KLQ, d.KQ >> 4, acc);
+        gemm_first(XQ, KLQ, d.KQ >> 4, acc);
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, h1T, B, row0);
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(0, 5);
     {
         f32x4 acc[4] = {};
@@ -505,7 +559,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         STAMP(0, 6);
         hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, h2T, B, row0);
     }
-    __syncthreads();
+    lds_barrier();
     // last_fc: q[row] = h2[row] . w3 + b3   (N = 1: VALU dot, 16 lanes per row)
     float s = 0.f;
 #pragma unroll
@@ -519,7 +573,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
 // K3: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through
 // Q1/Q2 down to d/da_new (input gradient only).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, int j) {
+__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B;
     float *X2 = lds;                 // dL/dh2 row-block [16][256]
@@ -538,15 +592,14 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     const float *h1T = d.QH1T + (size_t)pass * H * B;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
-    const float alpha = d.ctl->alpha;
-    float in_a = 0.f, in_b = 0.f, in_c = 0.f, in_r = 0.f, in_t = 0.f;
+    const float alpha = sload(&d.ctl->alpha);
+    float in_a = 0.f, in_b = 0.f, in_c = 0.f, in_r = 0.f, in_t = 0.f, in_q = 0.f;   // loads only: no use before SB
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
         if (critic) {
             in_a = d.q[4 * (size_t)B + r]; in_b = d.q[5 * (size_t)B + r]; in_c = d.logpi2[r];
             in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
-            in_a = fminf(in_a, in_b);
-            in_b = d.q[(size_t)qi * B + r];
+            in_q = d.q[(size_t)qi * B + r];
         } else {
             in_a = d.q[(size_t)(2 + qi) * B + r]; in_b = d.q[(size_t)(3 - qi) * B + r];
         }
@@ -570,14 +623,15 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         ra.fill(4);
     }
     SB();
+    USE_FROM_HERE(in_a); USE_FROM_HERE(in_b); USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t); USE_FROM_HERE(in_q);
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
         float dq;
         if (critic) {
-            const float tq = in_a - alpha * in_c;
+            const float tq = fminf(in_a, in_b) - alpha * in_c;
             const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
             if (qi == 0) d.y[r] = yv;
-            dq = 2.0f * (in_b - yv) * invB;
+            dq = 2.0f * (in_q - yv) * invB;
             d.dq16T[(size_t)qi * 16 * B + r] = dq;                  // row 0 of the padded [16][B]
         } else {
             const float sel = (in_a < in_b) ? 1.0f : ((in_a == in_b) ? 0.5f : 0.0f);   // torch.min backward
@@ -585,7 +639,7 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         }
         s_dq[threadIdx.x] = dq;
     }
-    __syncthreads();
+    lds_barrier();
     // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups)
     {
         float *outT = critic ? d.dQH2T + (size_t)qi * H * B : nullptr;
@@ -600,7 +654,7 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
             if (outT) st4(outT + (size_t)k * B + row0 + 4 * qd, gv);
         }
     }
-    __syncthreads();
+    lds_barrier();
     // dL/dh1 = (dL/dh2 . W2) * relu'(h1)
     {
         f32x4 acc[4] = {};
@@ -619,7 +673,7 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         }
     }
     if (critic) return;
-    __syncthreads();
+    lds_barrier();
     // d/da_new = dL/dh1 . W1[:, O:O+A]   -> da[qi][row][16]
     {
         f32x4 acc[1] = {};
@@ -649,13 +703,13 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
 
     STAMP(3, 0);
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
-    const float alpha = d.ctl->alpha;
+    const float alpha = sload(&d.ctl->alpha);
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int gi = (row0 + row) * 16 + a;
-    float act = 0.f, dav = 0.f, lsv = 0.f, epv = 0.f, okv = 0.f;
+    float act = 0.f, da1 = 0.f, da2 = 0.f, lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
     if (a < A) {
         act = d.anew[gi];
-        dav = d.da[gi] + d.da[(size_t)B * 16 + gi];
+        da1 = d.da[gi]; da2 = d.da[(size_t)B * 16 + gi];
         lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
     }
     SB();
@@ -675,11 +729,12 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
     for (int t = 0; t < 4; ++t) h1v[t] = ld4(d.PH1T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
-    __syncthreads();
+    lds_barrier();
     STAMP(3, 1);
+    USE_FROM_HERE(act); USE_FROM_HERE(da1); USE_FROM_HERE(da2); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
     if (a < A) {
         const float om = 1.0f - act * act;
-        const float dz = dav * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+        const float dz = (da1 + da2) * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
         const float stdv = expf(lsv);
         const float dls = (dz * stdv * epv - alpha * invB) * okv;
         XH[lds_off(row, a, 64)] = dz;
@@ -687,7 +742,7 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
         d.dheadT[(size_t)a * B + row0 + row] = dz;
         d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3, 2);
     {
         f32x4 acc[4] = {};
@@ -705,7 +760,7 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
             st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3, 4);
     {
         f32x4 acc[4] = {};
@@ -743,7 +798,7 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
 
 constexpr int NSTAT = 6;     // q1, q2, q_target, log_pi, mu, log_std
 
-__global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, int j) {
+__global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
     __shared__ float redb[4 * 16];
     const int B = d.B;
@@ -754,8 +809,17 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     if ((int)blockIdx.x < T.njobs) {
         int li = 0;
 #pragma unroll
-        for (int q = 1; q < NDW; ++q) li = ((int)blockIdx.x >= T.L[q].job0) ? q : li;
-        const DwLayer &J = T.L[li];
+        for (int q = 1; q < NDW; ++q) li = ((int)blockIdx.x >= T.job0[q]) ? q : li;
+        // the layer descriptor through the scalar cache (uniform index): one s_load burst, no vector
+        // load + readfirstlane round trip in front of the operand loads
+        union { DwLayer J; unsigned long long w[sizeof(DwLayer) / 8]; } ud;
+        {
+            const __attribute__((address_space(4))) unsigned long long *src =
+                (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(T.L + li);
+#pragma unroll
+            for (int q = 0; q < (int)(sizeof(DwLayer) / 8); ++q) ud.w[q] = src[q];
+        }
+        const DwLayer &J = ud.J;
         const int jj = blockIdx.x - J.job0;
         const int n0 = 16 * (jj / J.nk), k0 = 64 * (jj % J.nk);
         // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
@@ -772,15 +836,18 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         const float *xp = XT + (size_t)r * B + 4 * g;
         f32x4 acc[4] = {};
         float bsum = 0.f;
-        // first group of operand loads, then the owner's state, then the scalars: all in flight together
+        // first group of operand loads, then the owner's state, then the scalars: all in flight together.
+        // Loads are unconditional (clamped chunk index, select on the loaded VALUE): a conditional load
+        // becomes a branch whose merge point needs the data, i.e. a vmcnt(0) right behind the load.
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto chunk_of = [&](int sq) { const int m = (sq < s1 - 1) ? sq : s1 - 1; return m > 0 ? m : 0; };
         f32x4 a[4], b[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bool on = s0 + u < s1;
-            a[u] = on ? ld4(yp + 16 * (s0 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int cq = chunk_of(s0 + u);
+            a[u] = ld4(yp + 16 * cq);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                b[u][t] = on ? ld4(xp + (size_t)16 * t * B + 16 * (s0 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + (size_t)16 * t * B + 16 * cq);
         }
         f32x4 p4 = {0.f, 0.f, 0.f, 0.f}, m4 = p4, v4 = p4;
         if (own_valid) {
@@ -788,9 +855,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             m4 = ld4(J.MT + ot);
             v4 = ld4(J.VT + ot);
         }
-        const double bc1 = cp->bc1, bc2sd = cp->bc2s;
-        const long long step_now = cp->step_base + j;
-        const bool polyak = (J.TP != nullptr) && (step_now % d.period == 0);
+        const double bc1 = sload(&cp->bc1), bc2sd = sload(&cp->bc2s);
+        const bool polyak = (J.TP != nullptr) && (sa.step_now % d.period == 0);
         f32x4 tp4 = {0.f, 0.f, 0.f, 0.f};
         if (polyak && own_valid) {
 #pragma unroll
@@ -809,22 +875,22 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         for (int sI = s0; sI < s1; sI += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                bsum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+                const f32x4 au = (sI + u < s1) ? a[u] : zero4;
+                bsum += (au[0] + au[1]) + (au[2] + au[3]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][t][i], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[i], b[u][t][i], acc[t], 0, 0, 0);
                 }
             }
             if (sI + 4 < s1) {                       // batches above 256 rows: next group
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const bool on = sI + 4 + u < s1;
-                    a[u] = on ? ld4(yp + 16 * (sI + 4 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int cq = chunk_of(sI + 4 + u);
+                    a[u] = ld4(yp + 16 * cq);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        b[u][t] = on ? ld4(xp + (size_t)16 * t * B + 16 * (sI + 4 + u)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + (size_t)16 * t * B + 16 * cq);
                 }
             }
         }
@@ -833,7 +899,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         bsum += __shfl_xor(bsum, 16);
         bsum += __shfl_xor(bsum, 32);
         if (g == 0) redb[wave * 16 + r] = bsum;
-        __syncthreads();
+        lds_barrier();
         const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
         if (own_valid) {
             f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
@@ -866,8 +932,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         }
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
-        const float alpha = cp->alpha, alpha_loss = cp->alpha_loss;
-        const int loop_pos = cp->loop_base + j;
+        const float alpha = sload(&cp->alpha), alpha_loss = sload(&cp->alpha_loss);
+        const int loop_pos = sa.loop_pos;
         double sm[NSTAT], sq[NSTAT], ls4[4];
         float mx[NSTAT], mn[NSTAT];
 #pragma unroll
@@ -907,7 +973,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
             for (int q = 0; q < 4; ++q) sh[wave * 32 + 24 + q] = ls4[q];
         }
-        __syncthreads();
+        lds_barrier();
         if (threadIdx.x < NSTAT) {
             const int q = threadIdx.x;
             double s = 0, s2 = 0, MX = -INFINITY, MN = INFINITY;
@@ -944,15 +1010,6 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     }
 }
 
-// end of a chunk of n steps: advance the device-side counters (in stream order)
-__global__ void k_advance(Ctl *c, int n) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        c->step_base += n;
-        c->adam_base += n;
-        c->loop_base += n;
-    }
-}
-
 }  // namespace sac
 
 // ==========================================================================================
@@ -968,6 +1025,8 @@ struct sac_trainer {
     Net net[5];
     Dev dev{};
     DwTable dw{};
+    DwLayer *d_dwl = nullptr;
+    char *arena = nullptr;                            // the one device allocation everything lives in
     float *ws = nullptr; int64_t ws_floats = 0;      // all activations / gradients
     float *ext_slot = nullptr; SlotLayout ext_layout{};
     float *d_eps = nullptr;                           // [2][B*A]
@@ -979,6 +1038,8 @@ struct sac_trainer {
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
     size_t lds_pf = 0, lds_qf = 0, lds_qb = 0, lds_pb = 0;
+    void (*fwd_kernel)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
 };
 
 namespace {
@@ -997,9 +1058,29 @@ void build_layers(Net &n, const int (*shape)[2], int nl) {
     n.nP = off; n.nPT = offt;
 }
 
-int alloc_zero(float **p, long long n, hipStream_t s) {
-    SAC_HIP(hipMalloc(p, sizeof(float) * (size_t)n));
-    SAC_HIP(hipMemsetAsync(*p, 0, sizeof(float) * (size_t)n, s));
+// One arena for every device buffer of a trainer (weights, Adam state, activations, control words):
+// a single 2-MiB-aligned allocation keeps the whole working set (a few MB) on a handful of large
+// pages, so a kernel's first touches do not each pay an address-translation miss.
+struct Arena {
+    std::vector<std::pair<void **, size_t>> req;
+    size_t total = 0;
+    void reserve(void **p, size_t bytes) {
+        req.emplace_back(p, total);
+        total += (bytes + 255) & ~(size_t)255;
+    }
+};
+thread_local Arena *g_arena = nullptr;      // only during sac_trainer_create
+
+int alloc_zero(float **p, long long n, hipStream_t) {
+    g_arena->reserve(reinterpret_cast<void **>(p), sizeof(float) * (size_t)n);
+    return 0;
+}
+
+int arena_commit(Arena &a, char **base, hipStream_t s) {
+    const size_t bytes = (a.total + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    SAC_HIP(hipMalloc(reinterpret_cast<void **>(base), bytes));
+    SAC_HIP(hipMemsetAsync(*base, 0, bytes, s));
+    for (auto &r : a.req) *r.first = *base + r.second;
     return 0;
 }
 
@@ -1053,32 +1134,23 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
     const int NB = t->NB;
+    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0};
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_fwd<1>, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
-    else hipLaunchKernelGGL(k_fwd<2>, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, j);
+    hipLaunchKernelGGL(t->fwd_kernel, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, S, SL, j);
+    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, S, SL);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
     if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
     else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
     if (ev) SAC_HIP(hipEventRecord(ev[3], s));
-    hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, j);
+    hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
     if (ev) { SAC_HIP(hipEventRecord(ev[4], s)); SAC_HIP(hipEventRecord(ev[5], s)); }
     SAC_HIP(hipGetLastError());
+    t->n_train_steps_total += 1;
+    t->adam_t += 1;
     return 0;
 }
 
-int begin_loop(sac_trainer *t) {
-    int zero = 0;
-    SAC_HIP(hipMemcpyAsync(&t->d_ctl->loop_base, &zero, sizeof(int), hipMemcpyHostToDevice, t->stream));
-    return 0;
-}
-
-int advance(sac_trainer *t, int n) {
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, t->stream, t->d_ctl, n);
-    SAC_HIP(hipGetLastError());
-    return 0;
-}
 
 // sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
 int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
@@ -1116,6 +1188,8 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     hipStream_t s = t->stream;
     const int B = t->B;
 
+    Arena arena;
+    g_arena = &arena;
     const int shp[3][2] = {{H, t->O}, {H, H}, {2 * t->A, H}};
     const int shq[3][2] = {{H, t->O + t->A}, {H, H}, {1, H}};
     for (int i = 0; i < 5; ++i) {
@@ -1140,14 +1214,16 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     for (auto &p : parts) tot += round_up64(p.second, 64);
     if (alloc_zero(&t->ws, tot, s)) return -1;
     t->ws_floats = tot;
-    tot = 0;
-    for (auto &p : parts) { *p.first = t->ws + tot; tot += round_up64(p.second, 64); }
     t->ext_layout = make_slot_layout(B, t->O, t->A);
     if (alloc_zero(&t->ext_slot, t->ext_layout.slot_floats, s)) return -1;
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
-    SAC_HIP(hipMalloc(&t->d_ctl, sizeof(Ctl)));
-    SAC_HIP(hipMemsetAsync(t->d_ctl, 0, sizeof(Ctl), s));
+    arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
+    arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW);
+    g_arena = nullptr;
+    if (arena_commit(arena, &t->arena, s)) return -1;
+    tot = 0;
+    for (auto &p : parts) { *p.first = t->ws + tot; tot += round_up64(p.second, 64); }
 
     d.B = B; d.O = t->O; d.A = t->A; d.KP = t->KP; d.KQ = t->KQ; d.NH = t->NH; d.NB = t->NB;
     d.discount = cfg->discount; d.reward_scale = cfg->reward_scale; d.tau = cfg->soft_target_tau;
@@ -1163,10 +1239,12 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
 
     // weight-gradient work table: the 256x256 layers first (longest jobs)
     int nl = 0, job = 0;
+    std::vector<DwLayer> hl(NDW);
     auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr) {
         Net &n = t->net[netid];
         const Layer &L = n.L[l];
-        DwLayer &J = t->dw.L[nl++];
+        t->dw.job0[nl] = job;
+        DwLayer &J = hl[nl++];
         J.dYT = dYT; J.XT = XT; J.xt_from_slot = from_slot; J.xt_off = t->ext_layout.off_saT;
         J.P = n.P + L.offW; J.G = n.G + L.offW;
         J.PT = n.PT + L.offWt; J.MT = n.MT + L.offWt; J.VT = n.VT + L.offWt;
@@ -1191,6 +1269,9 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     add_layer(1, 2, d.dq16T, d.QH2T, 0, cfg->qf_lr);
     add_layer(2, 2, d.dq16T + (size_t)16 * B, d.QH2T + (size_t)H * B, 0, cfg->qf_lr);
     t->dw.njobs = job;
+    SAC_HIP(hipMemcpyAsync(t->d_dwl, hl.data(), sizeof(DwLayer) * NDW, hipMemcpyHostToDevice, s));
+    SAC_HIP(hipStreamSynchronize(s));      // hl is a local
+    t->dw.L = t->d_dwl;
 
     const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
@@ -1199,12 +1280,12 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     t->lds_qb = sizeof(float) * (size_t)(2 * RB * H + 1024);
     t->lds_pb = sizeof(float) * (size_t)(RB * 64 + RB * H);
     SAC_REQUIRE(t->lds_pf <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
-    if (t->lds_pf > 64 * 1024) {
-        if (nth == 1) SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd<1>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
-        else SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd<2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
-    }
+    const bool wide = t->KQ > 16 * RD0;
+    t->fwd_kernel = (nth == 1) ? (wide ? &k_fwd<1, true> : &k_fwd<1, false>)
+                               : (wide ? &k_fwd<2, true> : &k_fwd<2, false>);
+    if (t->lds_pf > 64 * 1024)
+        SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
     SAC_HIP(hipStreamSynchronize(s));
     *out = t;
     return 0;
@@ -1214,10 +1295,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->device);
     (void)hipStreamSynchronize(t->stream);
-    for (auto &n : t->net)
-        for (float *p : {n.P, n.M, n.V, n.PT, n.MT, n.VT, n.G}) (void)hipFree(p);
-    (void)hipFree(t->ws); (void)hipFree(t->ext_slot); (void)hipFree(t->d_eps); (void)hipFree(t->d_diag);
-    (void)hipFree(t->d_ctl);
+    (void)hipFree(t->arena);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
@@ -1307,7 +1385,7 @@ int sac_set_scalars(sac_trainer_t *t, const double sc[6]) {
     Ctl c;
     memset(&c, 0, sizeof(c));
     c.log_alpha = (float)sc[0]; c.a_m = (float)sc[1]; c.a_v = (float)sc[2];
-    c.adam_base = (long long)sc[3]; c.step_base = (long long)sc[4];
+    t->adam_t = (long long)sc[3]; t->n_train_steps_total = (long long)sc[4];
     c.alpha = t->cfg.use_automatic_entropy_tuning ? expf(c.log_alpha) : 1.0f;
     SAC_HIP(hipMemcpyAsync(t->d_ctl, &c, sizeof(c), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
@@ -1320,8 +1398,8 @@ int sac_get_scalars(sac_trainer_t *t, double sc[6]) {
     Ctl c;
     SAC_HIP(hipMemcpyAsync(&c, t->d_ctl, sizeof(c), hipMemcpyDeviceToHost, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    sc[0] = c.log_alpha; sc[1] = c.a_m; sc[2] = c.a_v; sc[3] = (double)c.adam_base;
-    sc[4] = (double)c.step_base; sc[5] = c.alpha;
+    sc[0] = c.log_alpha; sc[1] = c.a_m; sc[2] = c.a_v; sc[3] = (double)t->adam_t;
+    sc[4] = (double)t->n_train_steps_total; sc[5] = c.alpha;
     return 0;
 }
 
@@ -1361,9 +1439,7 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     } else {
         t->dev.eps1 = t->dev.eps2 = nullptr;
     }
-    if (begin_loop(t)) return -1;
     if (launch_step(t, t->ext_slot, L, 0)) return -1;
-    if (advance(t, 1)) return -1;
     if (diag) SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
     t->mirror_valid = false;
@@ -1380,11 +1456,9 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     t->dev.eps1 = t->dev.eps2 = nullptr;
     // 1) indices for every step, 2) one gather launch -> slots (buffer's stream), 3) the steps
     if (stage_batches(t, b, n_steps)) return -1;
-    if (begin_loop(t)) return -1;
     SAC_HIP(hipEventRecord(t->ev[0], s));
     for (int64_t i = 0; i < n_steps; ++i)
         if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i)) return -1;
-    if (advance(t, (int)n_steps)) return -1;
     SAC_HIP(hipEventRecord(t->ev[1], s));
     if (diag_first) SAC_HIP(hipMemcpyAsync(diag_first, t->dev.diag_first, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     if (diag_last) SAC_HIP(hipMemcpyAsync(diag_last, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
@@ -1404,13 +1478,11 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
     if (stage_batches(t, b, n_steps)) return -1;
-    if (begin_loop(t)) return -1;
     constexpr int NE = 6;            // e0 K1 e1 K2 e2 K3 e3 K4 e4 (nothing) e5
     std::vector<hipEvent_t> ev((size_t)n_steps * NE);
     for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
     for (int64_t i = 0; i < n_steps; ++i)
         if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * NE])) return -1;
-    if (advance(t, (int)n_steps)) return -1;
     SAC_HIP(hipStreamSynchronize(s));
     // interval k = launch k between two event records; the empty interval e4->e5 measures what an
     // event pair costs by itself and is subtracted from the four kernel intervals
