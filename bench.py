@@ -45,6 +45,20 @@ def flops_per_kernel(B, O, A):
     }
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_traffic.json; collected offline: PMC passes cannot run inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return (k.get("traffic_bytes_per_launch") if k else None), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def gather_bytes_per_step(B, O, A):
     return 2 * B * (2 * O + A + 2) * 4 + 8 * B                            # SURVEY.md section 8d
 
@@ -195,9 +209,11 @@ def main():
         kern["k_mt_randint"] = dict(ms=round(prof["k_mt_randint"], 5), indices=nprof * B)
         dom = max(fl, key=lambda k: prof[k])
         achieved = fl[dom] / (prof[dom] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom) if (B == 256 and O == 42) else (None, None)
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None,
-                        flops_per_launch=fl[dom], avg_launch_ms=round(prof[dom], 5),
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
+                        traffic_source=traffic_src, flops_per_launch=fl[dom], avg_launch_ms=round(prof[dom], 5),
+                        event_pair_ms=round(prof["event_pair"], 5),
                         whole_step=dict(gflop=round(sum(fl.values()) / 1e9, 4),
                                         tflops=round(sum(fl.values()) * value / world / 1e12, 3),
                                         frac=round(sum(fl.values()) * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5)))
@@ -218,6 +234,9 @@ def main():
                        "per_step": "MT19937 index draw + row gather + full SAC gradient step"},
             "device_ms": {k: round(v, 3) for k, v in dev_ms.items()},
             "roofline": roofline,
+            "roofline_gather": dict(bound="hbm", kernel="k_gather", achieved=kern["k_gather"]["gbs"], peak=PEAK_HBM_GBS,
+                                    unit="GB/s", frac=kern["k_gather"]["frac_hbm"],
+                                    algorithmic_bytes_per_step=gather_bytes_per_step(B, O, A), steps_per_launch=nprof),
             "kernels": kern,
             "per_gpu": per_gpu,
             "final": {"QF1 Loss": float(last[0]), "QF2 Loss": float(last[1]), "Alpha": float(last[28])},
