@@ -87,14 +87,46 @@ __global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, ui
 }
 
 // ------------------------------------------------------------------------------------------
-// k_gather: one 256-thread workgroup moves one 16-row block of one minibatch slot.
-//   HBM rows (16-B aligned, padded stride) --dwordx4--> LDS tile --dwordx4--> contiguous slot.
+// k_gather: persistent 256-thread workgroups, each moving 16-row blocks of minibatch slots:
+//   HBM rows (16-B aligned, padded stride) --dwordx4--> registers --> LDS tile --dwordx4--> slot.
 // The LDS tile lets the unpadded (B,O) output be written as full 16-B-per-lane coalesced stores
 // and lets the same rows be re-emitted feature-major (saT[KQ][B]) for the weight-gradient kernel.
+// Three-stage software pipeline per workgroup (indices of block n+2, rows of block n+1, write-out
+// of block n), so a workgroup always has a row burst in flight while it stores: the gather is
+// bound by bytes in flight per CU, not by the two dependent round trips (index -> row) per block.
+// Barriers wait for LDS only (a __syncthreads() would drain the prefetched rows).
 // ------------------------------------------------------------------------------------------
-template <typename T4>
-__device__ inline T4 ld16(const float *p) { return *reinterpret_cast<const T4 *>(p); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// LOAD_IDX / ISSUE_ROWS work on plain local arrays with static indices (structs passed by reference
+// into lambdas end up in scratch memory, and a scratch store of an in-flight load is a wait).
+#define GATHER_LOAD_IDX(BLK, IO, IA, IS)                                                          \
+    do {                                                                                          \
+        const int _b = (BLK);                                                                     \
+        const int _sl = _b / blocks_per_slot;                                                     \
+        const int64_t _base = (_b < nblk32) ? (int64_t)_sl * B + (_b - _sl * blocks_per_slot) * RB : 0; \
+        _Pragma("unroll") for (int i = 0; i < NIT; ++i) IO[i] = (int)idx[_base + (ro[i] >= 0 ? ro[i] : 0)]; \
+        IA = (int)idx[_base + (ra >= 0 ? ra : 0)];                                                \
+        IS = (int)idx[_base + (rs >= 0 ? rs : 0)];                                                \
+    } while (0)
+// the indices become "known" only here: otherwise the compiler hoists idx * stride up behind the
+// index load issued one phase earlier and waits (vmcnt(0)) in the middle of the write-out
+#define GATHER_ISSUE_ROWS(IO, IA, IS, DO, DN, DA_, DS, DS2)                                       \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < NIT; ++i) asm volatile("" : "+v"(IO[i]));            \
+        asm volatile("" : "+v"(IA));                                                              \
+        asm volatile("" : "+v"(IS));                                                              \
+        _Pragma("unroll") for (int i = 0; i < NIT; ++i) {                                         \
+            const int64_t _src = (int64_t)IO[i] * Ost + 4 * qo[i];                                \
+            DO[i] = *reinterpret_cast<const float4 *>(rv.obs + _src);                             \
+            DN[i] = *reinterpret_cast<const float4 *>(rv.nobs + _src);                            \
+        }                                                                                         \
+        DA_ = *reinterpret_cast<const float4 *>(rv.act + (int64_t)IA * Ast + 4 * qa);             \
+        DS = rv.rew[IS];  /* both unconditional: a conditional load is a branch whose merge */    \
+        DS2 = rv.term[IS]; /* point waits for the data */                                         \
+    } while (0)
+
+template <int NIT>      // obs 16-B chunks per thread: ceil(16 * (Ost/4) / 256)
 __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__restrict__ idx, int B,
                                                 int64_t n_blocks_total, float *__restrict__ slots,
                                                 SlotLayout L, int write_saT) {
@@ -103,37 +135,37 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
     float *t_obs = lds;                       // [16][Ost]
     float *t_nobs = t_obs + RB * Ost;         // [16][Ost]
     float *t_act = t_nobs + RB * Ost;         // [16][Ast]
-    __shared__ int64_t s_idx[RB];
     const int tid = threadIdx.x;
     const int blocks_per_slot = B / RB;
-    for (int64_t blk = blockIdx.x; blk < n_blocks_total; blk += gridDim.x) {
-        const int64_t slot = blk / blocks_per_slot;
-        const int row0 = (int)(blk % blocks_per_slot) * RB;
-        float *S = slots + slot * L.slot_floats;
-        __syncthreads();                      // previous iteration's LDS readers are done
-        if (tid < RB) s_idx[tid] = idx[slot * B + row0 + tid];
-        __syncthreads();
-        // ---- HBM -> LDS (16 B per lane) ----
-        const int oc = Ost >> 2, ac = Ast >> 2;          // 16-B chunks per row
-        for (int c = tid; c < RB * oc; c += 256) {
-            const int r = c / oc, q = c - r * oc;
-            const int64_t src = s_idx[r] * (int64_t)Ost + 4 * q;
-            *reinterpret_cast<float4 *>(t_obs + r * Ost + 4 * q) = ld16<float4>(rv.obs + src);
-            *reinterpret_cast<float4 *>(t_nobs + r * Ost + 4 * q) = ld16<float4>(rv.nobs + src);
-        }
-        for (int c = tid; c < RB * ac; c += 256) {
-            const int r = c / ac, q = c - r * ac;
-            *reinterpret_cast<float4 *>(t_act + r * Ast + 4 * q) =
-                ld16<float4>(rv.act + s_idx[r] * (int64_t)Ast + 4 * q);
-        }
-        if (tid < RB) {
-            S[L.off_rew + row0 + tid] = rv.rew[s_idx[tid]];
-        } else if (tid < 2 * RB) {
-            S[L.off_term + row0 + tid - RB] = rv.term[s_idx[tid - RB]];
-        }
-        __syncthreads();
-        // ---- LDS -> contiguous row-major slot (16*O floats = 64*O bytes, 16-B aligned) ----
-        {
+    const int oc = Ost >> 2, ac = Ast >> 2;   // 16-B chunks per row
+    const int nblk32 = (int)n_blocks_total;   // launch_gather caps the block count below 2^30
+    // this thread's fixed share of a block: obs chunks c_i = tid + 256 i, one act chunk, one scalar
+    int ro[NIT], qo[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int c = tid + 256 * i;
+        ro[i] = (c < RB * oc) ? c / oc : -1;
+        qo[i] = (c < RB * oc) ? c - ro[i] * oc : 0;
+    }
+    const int ra = (tid < RB * ac) ? tid / ac : -1, qa = (tid < RB * ac) ? tid - ra * ac : 0;
+    const int rs = (tid < 2 * RB) ? (tid & (RB - 1)) : -1;         // tid < 16: reward, 16..31: terminal
+
+    // stage C: registers of one block -> LDS tile -> slot
+    auto write_out = [&](int blk, const float4 (&Do)[NIT], const float4 (&Dn)[NIT], const float4 &Da, float Ds,
+                         float Ds2) {
+        const int slot = blk / blocks_per_slot;
+        const int row0 = (blk - slot * blocks_per_slot) * RB;
+        float *S = slots + (int64_t)slot * L.slot_floats;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            if (ro[i] >= 0) {
+                *reinterpret_cast<float4 *>(t_obs + ro[i] * Ost + 4 * qo[i]) = Do[i];
+                *reinterpret_cast<float4 *>(t_nobs + ro[i] * Ost + 4 * qo[i]) = Dn[i];
+            }
+        if (ra >= 0) *reinterpret_cast<float4 *>(t_act + ra * Ast + 4 * qa) = Da;
+        if (rs >= 0) S[(tid < RB ? L.off_rew : L.off_term) + row0 + rs] = (tid < RB) ? Ds : Ds2;
+        lds_barrier();
+        {   // LDS -> contiguous row-major slot (16*O floats = 64*O bytes, 16-B aligned)
             float *dst = S + L.off_obs + (int64_t)row0 * O;
             float *dstn = S + L.off_nobs + (int64_t)row0 * O;
             const int n4 = (RB * O) >> 2;
@@ -164,8 +196,7 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                 *reinterpret_cast<float4 *>(dsta + 4 * c) = a;
             }
         }
-        // ---- LDS -> feature-major saT[f][row0 .. row0+15] ----
-        if (write_saT) {
+        if (write_saT) {   // LDS -> feature-major saT[f][row0 .. row0+15]
             float *T = S + L.off_saT;
             for (int c = tid; c < (O + A) * 4; c += 256) {
                 const int f = c >> 2, q = c & 3;
@@ -179,8 +210,33 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                 *reinterpret_cast<float4 *>(T + (int64_t)f * B + row0 + 4 * q) = v;
             }
         }
+        lds_barrier();                             // tile free for the next block
+    };
+
+    // Two register sets, ping-pong (no copies: copying an in-flight load's destination is a wait).
+    const int stride = gridDim.x;
+    int io0[NIT], io1[NIT], ia0, ia1, is0, is1;
+    float4 oA[NIT], nA[NIT], aA, oB[NIT], nB[NIT], aB;
+    float sA, s2A, sB, s2B;
+    int blk = blockIdx.x;
+    GATHER_LOAD_IDX(blk, io0, ia0, is0);
+    GATHER_LOAD_IDX(blk + stride, io1, ia1, is1);
+    GATHER_ISSUE_ROWS(io0, ia0, is0, oA, nA, aA, sA, s2A);
+    for (; blk < nblk32; blk += 2 * stride) {
+        GATHER_LOAD_IDX(blk + 2 * stride, io0, ia0, is0);          // stage A: indices two blocks ahead
+        GATHER_ISSUE_ROWS(io1, ia1, is1, oB, nB, aB, sB, s2B);     // stage B: next block's rows into flight
+        __builtin_amdgcn_sched_barrier(0);
+        write_out(blk, oA, nA, aA, sA, s2A);                       // stage C
+        if (blk + stride < nblk32) {
+            GATHER_LOAD_IDX(blk + 3 * stride, io1, ia1, is1);
+            GATHER_ISSUE_ROWS(io0, ia0, is0, oA, nA, aA, sA, s2A);
+            __builtin_amdgcn_sched_barrier(0);
+            write_out(blk + stride, oB, nB, aB, sB, s2B);
+        }
     }
 }
+#undef GATHER_LOAD_IDX
+#undef GATHER_ISSUE_ROWS
 
 int ensure_stage(sac_buffer *b, size_t bytes) {
     if (b->stage_bytes >= bytes) return 0;
@@ -221,19 +277,21 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
     return 0;
 }
 
-int launch_sample(sac_buffer *b, int batch, int64_t n_batches) {
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset) {
     const int64_t count = (int64_t)batch * n_batches;
     SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
     SAC_REQUIRE(b->size - 1 <= 0xffffffffLL, "replay buffers above 2^32 slots are not supported");
-    if (ensure_idx(b, count)) return -1;
+    if (idx_offset == 0 && ensure_idx(b, count)) return -1;
+    SAC_REQUIRE(idx_offset + count <= b->idx_cap, "index buffer too small for this offset");
     const uint32_t rng = (uint32_t)(b->size - 1);
     if (rng == 0) {     // NumPy: no draws consumed, all zeros
-        SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * count, b->stream));
+        SAC_HIP(hipMemsetAsync(b->d_idx + idx_offset, 0, sizeof(int64_t) * count, b->stream));
         return 0;
     }
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, b->d_idx);
+    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count,
+                       b->d_idx + idx_offset);
     SAC_HIP(hipGetLastError());
     return 0;
 }
@@ -242,11 +300,20 @@ int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batc
                   const SlotLayout &L, int write_saT) {
     SAC_REQUIRE(batch > 0 && batch % RB == 0, "batch size %d must be a positive multiple of %d", batch, RB);
     const int64_t nblk = (int64_t)(batch / RB) * n_batches;
-    const int grid = (int)(nblk < 16384 ? nblk : 16384);
+    SAC_REQUIRE(nblk < (1LL << 30), "too many rows in one gather launch");
+    const int grid = (int)(nblk < 1024 ? nblk : 1024);          // 4 persistent workgroups per CU (VGPR-limited)
     const size_t lds = sizeof(float) * (size_t)(2 * RB * b->Ost + RB * b->Ast);
-    SAC_REQUIRE(lds <= 160 * 1024 - 256, "observation rows too wide for the gather tile (%zu B LDS)", lds);
-    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), lds, b->stream, b->view(), d_idx, batch, nblk, d_slots, L,
-                       write_saT);
+    SAC_REQUIRE(lds <= 64 * 1024, "observation rows too wide for the gather tile (%zu B LDS)", lds);
+    const int nit = (RB * (b->Ost >> 2) + 255) / 256;            // obs chunks per thread
+    SAC_REQUIRE(nit <= 8, "observation rows too wide for the gather kernel (obs_dim %d)", b->O);
+#define SAC_GATHER_LAUNCH(N)                                                                               \
+    hipLaunchKernelGGL(k_gather<N>, dim3(grid), dim3(256), lds, b->stream, b->view(), d_idx, batch, nblk, \
+                       d_slots, L, write_saT)
+    if (nit <= 1) SAC_GATHER_LAUNCH(1);
+    else if (nit <= 2) SAC_GATHER_LAUNCH(2);
+    else if (nit <= 4) SAC_GATHER_LAUNCH(4);
+    else SAC_GATHER_LAUNCH(8);
+#undef SAC_GATHER_LAUNCH
     SAC_HIP(hipGetLastError());
     return 0;
 }

@@ -212,17 +212,24 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 f32x4 bc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bc[t] = R.b[u][t];
+#ifndef SAC_ABLATE_LOADS
                 if (S + D < KS) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + CHUNK_STRIDE * R.chunk(S + D));
                 }
+#endif
                 SB();
+#ifndef SAC_ABLATE_MFMA
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], bc[t][i], acc[t], 0, 0, 0);
                 }
+#else
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { asm volatile("" :: "v"(bc[t])); acc[t] += bc[t] * a_cur; }
+#endif
                 SB();
                 a_cur = a_nxt;
             }
@@ -701,6 +708,15 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
     const float *PT = d.PT[0];
     const float invB = 1.0f / (float)B;
 
+#ifdef SAC_EXPERIMENT_PRETOUCH
+    {   // timing experiment: pull the whole W1^T through this XCD's L2 first (results unchanged)
+        const float *Wp = PT + d.LP[1].offWt;
+        f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+        for (int e = threadIdx.x; e < H * H / 4; e += 256) sink += ld4(Wp + 4 * e);
+        if (sink[0] == 12345.678f) d.dheadT[0] = sink[1];
+        lds_barrier();
+    }
+#endif
     STAMP(3, 0);
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const float alpha = sload(&d.ctl->alpha);
@@ -1034,6 +1050,7 @@ struct sac_trainer {
     Ctl *d_ctl = nullptr;
     void *h_stage = nullptr; size_t stage_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // slot double buffer
     float last_ms[4] = {0, 0, 0, 0};
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
@@ -1185,6 +1202,8 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     t->NB = t->B / 16;
     SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
+    for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     hipStream_t s = t->stream;
     const int B = t->B;
 
@@ -1298,6 +1317,8 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     (void)hipFree(t->arena);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : t->ev_ready) if (e) (void)hipEventDestroy(e);
+    for (auto &e : t->ev_done) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(t->stream);
     delete t;
     return 0;
@@ -1454,11 +1475,33 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    // 1) indices for every step, 2) one gather launch -> slots (buffer's stream), 3) the steps
-    if (stage_batches(t, b, n_steps)) return -1;
+    // Chunks of CH steps, slots double-buffered: while the trainer's stream runs the steps of chunk
+    // c, the buffer's stream draws the indices of chunk c+1 (one serial wave) and gathers its slots.
+    // The index stream is one in-order sequence on the buffer's stream, so it consumes NumPy's
+    // generator exactly like n_steps random_batch calls.
+    const int64_t CH = 256;
+    const int64_t n_chunks = (n_steps + CH - 1) / CH;
+    const int64_t n_slots = n_steps < 2 * CH ? n_steps : 2 * CH;
+    if (ensure_slots(b, t->B, n_slots)) return -1;
+    if (ensure_idx(b, n_slots * t->B)) return -1;
     SAC_HIP(hipEventRecord(t->ev[0], s));
-    for (int64_t i = 0; i < n_steps; ++i)
-        if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i)) return -1;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        const int64_t first = c * CH, m = (n_steps - first < CH) ? n_steps - first : CH;
+        const int half = (int)(c & 1);
+        const int64_t slot0 = (n_chunks == 1) ? 0 : half * CH;
+        if (c >= 2) SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[half], 0));   // trainer is done with this half
+        if (c == 0) SAC_HIP(hipEventRecord(b->ev[0], b->stream));
+        if (launch_sample(b, t->B, m, slot0 * t->B)) return -1;
+        if (c == 0) SAC_HIP(hipEventRecord(b->ev[1], b->stream));
+        if (launch_gather(b, b->d_idx + slot0 * t->B, t->B, m, b->d_slots + (size_t)slot0 * b->slot.slot_floats, b->slot, 1))
+            return -1;
+        if (c == 0) SAC_HIP(hipEventRecord(b->ev[2], b->stream));
+        SAC_HIP(hipEventRecord(t->ev_ready[half], b->stream));
+        SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[half], 0));
+        for (int64_t i = 0; i < m; ++i)
+            if (launch_step(t, b->d_slots + (size_t)(slot0 + i) * b->slot.slot_floats, b->slot, (int)(first + i))) return -1;
+        SAC_HIP(hipEventRecord(t->ev_done[half], s));
+    }
     SAC_HIP(hipEventRecord(t->ev[1], s));
     if (diag_first) SAC_HIP(hipMemcpyAsync(diag_first, t->dev.diag_first, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     if (diag_last) SAC_HIP(hipMemcpyAsync(diag_last, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
@@ -1466,7 +1509,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipEventElapsedTime(&t->last_ms[1], b->ev[0], b->ev[1]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[2], b->ev[1], b->ev[2]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));
-    SAC_HIP(hipEventElapsedTime(&t->last_ms[0], b->ev[0], t->ev[1]));
+    t->last_ms[0] = t->last_ms[3];            // sampling + gathering of later chunks overlap the steps
     t->mirror_valid = false;
     return 0;
 }

@@ -18,7 +18,8 @@ def filled_buffer(n, O, A, seed):
     return buf
 
 
-@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 128, 25), (42, 7, 256, 12), (89, 14, 256, 6)])
+# 600 steps: three chunks of the double-buffered slot ring (chunk 2 reuses chunk 0's half)
+@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 128, 25), (42, 7, 256, 12), (89, 14, 256, 6), (10, 3, 32, 600)])
 def test_fused_loop_equals_stepwise_interface(O, A, B, steps):
     n = 10_000
     _, fused = make_pair(O, A, B, seed=4, noise_seed=77)
