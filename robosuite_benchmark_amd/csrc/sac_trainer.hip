@@ -117,7 +117,6 @@ __device__ unsigned long long g_stamps[5 * 512 * 16];
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (threadIdx.x == 0 && blockIdx.x < 512) {                                                \
             g_stamps[((kid) * 512 + blockIdx.x) * 16 + (i)] = wall_clock64();                      \
-            g_stamps[((kid) * 512 + blockIdx.x) * 16 + 8 + (i)] = clock64();                       \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
@@ -442,8 +441,10 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         {
             f32x4 acc[4] = {};
             gemm_first(XP, KLP, d.KP >> 4, acc);
+            STAMP(0, 8);
             rh.fill(4);
             hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (pass == 2) ? d.PH1T : nullptr, B, row0);
+            STAMP(0, 9);
             issue_q_first();               // r0 / rows / bv0 are free again: start the Q net's stream
             SB();
         }
@@ -454,15 +455,19 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
             gemm_ring(r1, X1, H, H >> 4, acc);
             STAMP(0, 3);
             hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, (pass == 2) ? d.PH2T : nullptr, B, row0);
+            STAMP(0, 10);
             issue_q_second();
             SB();
         }
         lds_barrier();
+        STAMP(0, 11);
         {
             f32x4 acc[NTH] = {};
             gemm_ring(rh, X2, H, 4, acc, 4 * wave);
+            STAMP(0, 12);
             splitk_reduce<NTH>(acc, PP + d.LP[2].offB, red, HD, 32);
         }
+        STAMP(0, 13);
         rows.commit(XQ, KLQ, d.KQ, O, O + A);   // obs part + zero padding; the head below writes the action columns
         // tanh-Gaussian head: thread = (row, a)
         const int a = part, grow = row0 + row;
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S,
         } else if (pass == 4) {
             d.a2[grow * 16 + a] = 0.f;
         }
+        STAMP(0, 14);
         const float lsum = group16_sum(lp);
         if (owner && a == 0) (next ? d.logpi2 : d.logpi)[grow] = lsum;
         if (pass == 2 && a == 0) red[row] = lsum;

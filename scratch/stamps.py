@@ -10,17 +10,10 @@ out = np.zeros(5*512*16, np.uint64)
 lib.sac_fetch_stamps.argtypes = [C.c_void_p, C.c_void_p]
 lib.sac_fetch_stamps(tr._h, out.ctypes.data_as(C.c_void_p))
 st = out.reshape(5, 512, 16).astype(np.int64)
-for kid, nb in ((0,96),(3,16)):
-    w = st[kid, :nb, :8]; c = st[kid, :nb, 8:]
-    if w[:,0].max() == 0: continue
-    t0 = w[:,0].min()
-    print("kernel", kid, "blocks", nb, "start spread (us)", (w[:,0].max()-t0)/100.0)
-    nz = [i for i in range(8) if w[:,i].max() > 0]
-    for i in nz[1:]:
-        dw = (w[:,i]-w[:,i-1])/100.0; dc = (c[:,i]-c[:,i-1])
-        print(f"  seg {i-1}->{i}: wall us median {np.median(dw):.2f} max {dw.max():.2f} | cycles median {np.median(dc):.0f} | MHz {np.median(dc/np.maximum(dw,0.01)):.0f}")
-    print("  total per block us: median", np.median((w[:,nz[-1]]-w[:,0])/100.0), " last end - first start:", (w[:,nz[-1]].max()-t0)/100.0)
-    if kid == 0:
-        for p in range(6):
-            ww = w[16*p:16*p+16]
-            print("   pass", p, "start", np.round((ww[:,0].min()-t0)/100.0,2), "segs", [float(np.round(np.median((ww[:,i]-ww[:,i-1])/100.0),2)) if ww[:,i].max()>0 and ww[:,i-1].max()>0 else None for i in range(1,8)], "end", np.round((ww[:,7].max()-t0)/100.0,2))
+order = [0,1,8,9,2,3,10,11,12,13,14,4,5,6,7]
+names = ["start","prologue+sync","piG0","epi0","issueQ1+sync","piG1","epi1","issueQ2+sync","headG","reduce","commit+elem","tail(ticket)+sync","QG0+epi+sync","QG1","end"]
+w = st[0,:96]
+for p_ in range(2,6):
+    ww = w[16*p_:16*p_+16]
+    t = [np.median(ww[:,i]) for i in order]
+    print("pass", p_, " ".join(f"{names[k+1]}={(t[k+1]-t[k])/100.0:.2f}" for k in range(len(order)-1)), " total", (t[-1]-t[0])/100.0)
