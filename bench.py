@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--buffer", type=int, default=1_000_000)
     ap.add_argument("--sweep", action="store_true", help="N>1: 8-task sweep (BASELINE configs[4]) instead of seeds")
+    ap.add_argument("--task", type=str, default=None,
+                    help="N=1 only: another task of the sweep table (e.g. Door, TwoArmHandoff); default Lift")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=500)
     args = ap.parse_args()
@@ -167,6 +169,8 @@ def main():
         dist = parallel.init_process_group("nccl", local_rank)      # nccl == RCCL on ROCm
 
     task, O, A, seed = parallel.task_for_rank(rank, sweep=args.sweep and world > 1)
+    if args.task is not None and world == 1:
+        task, O, A = next(t for t in parallel.SWEEP + [("TwoArmLift", 89, 14)] if t[0] == args.task)
     B = args.batch
     trainer, buf = build_replica(task, O, A, B, args.buffer, seed=seed, device=local_rank)
 

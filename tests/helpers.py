@@ -45,3 +45,39 @@ def make_pair(O, A, B, seed=3, device=0, **kw):
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def layers_from_flat(flat, shapes):
+    """flat nn.Linear vector (W, b per layer) -> [(W, b), ...] for the oracle."""
+    out, off = [], 0
+    for (n, k) in shapes:
+        w = np.asarray(flat[off:off + n * k], np.float32).reshape(n, k).copy(); off += n * k
+        b = np.asarray(flat[off:off + n], np.float32).copy(); off += n
+        out.append((w, b))
+    assert off == len(flat)
+    return out
+
+
+def make_pair_from_flat(flats, O, A, B, device=0, **kw):
+    """Oracle + HIP trainer from flat parameter vectors {policy, qf1, qf2[, target_qf1, target_qf2]}."""
+    from collections import OrderedDict
+    from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy
+    kw.setdefault("policy_lr", 1e-3)
+    kw.setdefault("qf_lr", 5e-4)
+    kw.setdefault("soft_target_tau", 0.005)
+    kw.setdefault("target_update_period", 5)
+    qs, ps = [(256, O + A), (256, 256), (1, 256)], [(256, O), (256, 256), (A, 256), (A, 256)]
+    nets = OrderedDict()
+    for name in ("qf1", "qf2", "target_qf1", "target_qf2"):
+        nets[name] = layers_from_flat(flats.get(name, flats[name.replace("target_", "")]), qs)
+    nets["policy"] = layers_from_flat(flats["policy"], ps)
+    noise_seed = kw.pop("noise_seed", 0)
+    oracle = RlkitEquivalentSAC(nets, A, **kw)
+    pol = TanhGaussianPolicy([256, 256], O, A)
+    pol.load_flat(flat_of(nets["policy"]))
+    qn = [FlattenMlp([256, 256], 1, O + A) for _ in range(4)]
+    for q, name in zip(qn, ("qf1", "qf2", "target_qf1", "target_qf2")):
+        q.load_flat(flat_of(nets[name]))
+    hip = SACTrainer(policy=pol, qf1=qn[0], qf2=qn[1], target_qf1=qn[2], target_qf2=qn[3], batch_size=B,
+                     device=device, noise_seed=noise_seed, **kw)
+    return oracle, hip
