@@ -11,10 +11,12 @@
 // grid barrier on 8 XCDs); the weight-gradient kernel is tile-owner parallel and applies Adam and
 // the Polyak update in its epilogue, so gradients never round-trip through HBM.
 //
-//   K1 k_fwd          6*B/16 WGs   pi(s) -> Q1,Q2(s,a_new); pi(s') -> T1,T2(s',a'); Q1,Q2(s,a); alpha step
-//   K2 k_q_bwd        4*B/16 WGs   critic dL/dh (2 nets), actor dQ/da (2 nets)
-//   K3 k_policy_bwd     B/16 WGs   head gradient (reparameterised), dL/dh
-//   K4 k_dw_adam      ~250  WGs    dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
+//   A k_fwd_a       16*B/16 WGs   pi(s), pi(s') -> head partials; Q1,Q2(s,a) -> q partials
+//   B k_fwd_b       16*B/16 WGs   tanh-Gaussian head, alpha step; Q1,Q2(s,a_new), T1,T2(s',a') -> q partials
+//   C k_q_bwd       16*B/16 WGs   critic dL/dh (2 nets), actor dQ/da partials (2 nets)
+//   D k_policy_bwd   4*B/16 WGs   head gradient (reparameterised), dL/dh
+//   E k_dw_adam     ~250  WGs     dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
+// (every 256-wide layer is split over 4 workgroups per 16-row block; partial sums meet at launch boundaries)
 //
 // Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round
 // trips, not by FLOPs): the minibatch slot and the step index are launch arguments (no dependent
@@ -87,7 +89,9 @@ struct Dev {
     // Q forward: passes 0..3 keep h1/h2 feature-major; q values for all 6 passes
     float *QH1T, *QH2T, *q;
     // backward
-    float *y, *dq16T, *dQH2T, *dQH1T, *da, *dheadT, *dPH2T, *dPH1T;
+    float *y, *dq16T, *dQH2T, *dQH1T, *dheadT, *dPH2T, *dPH1T;
+    // partial sums of the column-split layers (added by the consuming launch, fixed order)
+    float *headpart, *qpart, *dapart;
     // diagnostics
     float *diag_first, *diag_last, *diag_trace;
     // caller-supplied noise (NULL => counter-based device stream)
@@ -360,240 +364,279 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: the whole forward pass.  pass = blockIdx / NB, one 16-row block each:
-//   0 Q1(s,a)   1 Q2(s,a)   2 pi(s) -> Q1(s,a_new)   3 pi(s) -> Q2(s,a_new)
-//   4 pi(s') -> T1(s',a')   5 pi(s') -> T2(s',a')
-// Rows are independent, so a block that needs the policy's action for its rows simply runs the
-// policy for those rows itself (passes 3 and 5 repeat the tiny policy forward of passes 2 and 4
-// bit-for-bit; only the owner passes 2 / 4 write the policy's outputs).  That removes the kernel
-// boundary + cold-cache round trip between "policy forward" and "Q forward".  The weights of the
-// second network are requested while the first one is still computing.
-// The last owner block to finish (arrival ticket, release/acquire at agent scope, no spinning)
-// reduces sum(log_pi) in a fixed order and performs the alpha Adam step (SURVEY Appendix A
-// lines 4-6); it also publishes this step's Adam bias corrections for the weight-gradient kernel.
+// Step kernels.  Every 256-wide hidden layer is split over SPLIT = 4 workgroups per 16-row block
+// (64 output columns = one MFMA tile per wave): a CU's fill path sustains only ~20 B/clk, so the
+// 256 KB of a 256x256 layer cost one CU 5.7 us but four CUs 1.4 us each.  No CU ever waits for
+// another one inside a launch: the small first layers are recomputed by all four workgroups
+// (their input is the whole row), and what follows a split layer is always a contraction over its
+// columns (head, q value, d/da), so each workgroup emits a PARTIAL sum over its 64 columns and the
+// consumer -- always the next launch -- adds the four partials in a fixed order.
+//
+//   A k_fwd_a   16*B/16 WGs  pi(s), pi(s') -> head partials;   Q1,Q2(s,a) -> q partials
+//   B k_fwd_b   16*B/16 WGs  tanh-Gaussian head (from the partials), alpha step (last arriver);
+//                            Q1,Q2(s,a_new), T1,T2(s',a') -> q partials
+//   C k_q_bwd   16*B/16 WGs  q = sum of partials; critic dL/dh (kept for dW), actor d/da partials
+//   D k_pi_bwd   4*B/16 WGs  head gradient (reparameterised, analytic), dL/dh
+//   E k_dw_adam              (below)
 // ------------------------------------------------------------------------------------------
+constexpr int SPLIT = 4;
+
+// relu(acc + bias) of this wave's single tile -> local slice buffer XS[16][64] and (optionally) the
+// feature-major global row of that feature
+__device__ __forceinline__ void slice_epilogue(const f32x4 &acc, float bv, int wave, float *XS, float *outT_row,
+                                               int row0) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = fmaxf(acc[i] + bv, 0.f);
+        XS[lds_off(4 * g + i, 16 * wave + c, 64)] = v[i];
+    }
+    if (outT_row) st4(outT_row + row0 + 4 * g, v);
+}
+
 template <int NTH, bool WIDE>
-__global__ __launch_bounds__(256) void k_fwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+__global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ S, SlotLayout SL) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int B = d.B, O = d.O, A = d.A;
-    const int KLP = (d.KP + 63) & ~63, KLQ = (d.KQ + 63) & ~63;
-    float *XP = lds;                     // [16][KLP]  policy input row-block
-    float *XQ = XP + RB * KLP;           // [16][KLQ]  Q input row-block cat(obs, action)
-    float *X1 = XQ + RB * KLQ;           // [16][256]
-    float *X2 = X1 + RB * H;             // [16][256]
-    float *HD = X2 + RB * H;             // [16][32]
-    float *red = HD + RB * 32;           // split-K scratch 4*NTH*256
-    const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
+    const int B = d.B, O = d.O, A = d.A, NB = d.NB;
+    const int KLmax = (d.KQ + 63) & ~63;
+    float *X0 = lds;                     // [16][KL0]
+    float *X1 = X0 + RB * KLmax;         // [16][256]  full first hidden layer
+    float *XS = X1 + RB * H;             // [16][64]   this block's 64 columns of the second one
+    float *red = XS + RB * 64;           // split-K scratch 4*NTH*256
+    const int npi = 2 * SPLIT * NB;
+    const bool is_pi = (int)blockIdx.x < npi;
+    const int b = is_pi ? blockIdx.x : blockIdx.x - npi;
+    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, sq = (b >> 2) / NB;   // sq: side (pi) / twin (Q)
     const int row0 = rb * RB;
-    const bool has_pi = pass >= 2, next = pass >= 4, owner = (pass == 2) || (pass == 4);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
-    const int row = threadIdx.x >> 4, part = threadIdx.x & 15;
-    const float *PP = d.P[0];
-    const float *PQ = d.P[(pass < 4) ? 1 + (pass & 1) : 3 + (pass & 1)];
-    const float *obs = S + (next ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
+    const int row = threadIdx.x >> 4, p16 = threadIdx.x & 15;
+    const float *P = is_pi ? d.P[0] : d.P[1 + sq];
+    const Layer L0 = is_pi ? d.LP[0] : d.LQ[0], L1 = is_pi ? d.LP[1] : d.LQ[1], L2 = is_pi ? d.LP[2] : d.LQ[2];
+    const int K0 = is_pi ? d.KP : d.KQ, KL0 = (K0 + 63) & ~63;
+    const int n0 = 64 * part + 16 * wave;                    // this wave's tile of the split layer
+    const float *obs = S + ((is_pi && sq) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
 
-    WRing<4, WIDE ? RD : RD0> r0;          // WIDE: obs+act > 128 (Wipe): generic ring loop
-    WRing<4, RDH4> r1;
-    WRing<NTH> rh;
+    // ---- requests, in consumption order ----
     RowRegs<WIDE ? 32 : 8> rows;
-    float bv0[4], bv1[4], w3[16], b3 = 0.f;
-    auto gemm_first = [&](const float *X, int KL, int KS, f32x4 (&acc)[4]) {
-        if constexpr (WIDE) gemm_ring(r0, X, KL, KS, acc);
-        else gemm_straight(r0, X, KL, KS, acc);
-    };
-    auto issue_q_first = [&]() {       // Q net: input rows, first layer, its bias
-        rows.issue(d.KQ, obs, O, O, S + SL.off_act + (size_t)row0 * A, (pass < 2) ? A : 0, A);
-        r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
-        r0.fill(d.KQ >> 4);
+    rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, is_pi ? 0 : A, A);
+    WRing<4, WIDE ? RD : RD0> r0;
+    r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
+    r0.fill(K0 >> 4);
+    float bv0[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
-    };
-    auto issue_q_second = [&]() {      // Q net: hidden layer stream, biases, output layer
-        r1.init(PQ + d.LQ[1].offW, H, 64 * wave, 16);
-        r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
-        r1.fill(H >> 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv1[t] = PQ[d.LQ[1].offB + 64 * wave + 16 * t + c];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) w3[u] = PQ[d.LQ[2].offW + part + 16 * u];
-        b3 = PQ[d.LQ[2].offB];
-    };
-
-    STAMP(0, 0);
-    if (has_pi) {
-        // ---- policy on this block's rows ----
-        rows.issue(d.KP, obs, O, O, nullptr, 0, 0);
-        r0.init(PP + d.LP[0].offW, d.LP[0].Kp, 64 * wave, 16);
-        r0.fill(d.KP >> 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv0[t] = PP[d.LP[0].offB + 64 * wave + 16 * t + c];
-        SB();
-        r1.init(PP + d.LP[1].offW, H, 64 * wave, 16);
-        r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
-        r1.fill(H >> 4);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv1[t] = PP[d.LP[1].offB + 64 * wave + 16 * t + c];
-        rh.init(PP + d.LP[2].offW, H, 0, 16, 4 * wave);    // head: contraction split over the waves
-        SB();
-        rows.commit(XP, KLP, d.KP);
-        lds_barrier();
-        STAMP(0, 1);
-        {
-            f32x4 acc[4] = {};
-            gemm_first(XP, KLP, d.KP >> 4, acc);
-            STAMP(0, 8);
-            rh.fill(4);
-            hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (pass == 2) ? d.PH1T : nullptr, B, row0);
-            STAMP(0, 9);
-            issue_q_first();               // r0 / rows / bv0 are free again: start the Q net's stream
-            SB();
-        }
-        lds_barrier();
-        STAMP(0, 2);
-        {
-            f32x4 acc[4] = {};
-            gemm_ring(r1, X1, H, H >> 4, acc);
-            STAMP(0, 3);
-            hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, (pass == 2) ? d.PH2T : nullptr, B, row0);
-            STAMP(0, 10);
-            issue_q_second();
-            SB();
-        }
-        lds_barrier();
-        STAMP(0, 11);
-        {
-            f32x4 acc[NTH] = {};
-            gemm_ring(rh, X2, H, 4, acc, 4 * wave);
-            STAMP(0, 12);
-            splitk_reduce<NTH>(acc, PP + d.LP[2].offB, red, HD, 32);
-        }
-        STAMP(0, 13);
-        rows.commit(XQ, KLQ, d.KQ, O, O + A);   // obs part + zero padding; the head below writes the action columns
-        // tanh-Gaussian head: thread = (row, a)
-        const int a = part, grow = row0 + row;
-        float lp = 0.f;
-        if (a < A) {
-            const float mean = HD[row * 32 + a];
-            const float raw = HD[row * 32 + A + a];
-            const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-            const float stdv = expf(lstd);
-            const float *epp = next ? d.eps2 : d.eps1;
-            const float eps = epp ? epp[grow * A + a]
-                                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now,
-                                                  (unsigned)(grow * 16 + a), next ? 1u : 0u);
-            const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
-            const float act = tanhf(zz);
-            const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
-            const float var = __fmul_rn(stdv, stdv);
-            const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
-            lp = nlp - logf(1.0f - act * act + TANH_EPS);
-            XQ[lds_off(row, O + a, KLQ)] = act;
-            if (pass == 2) {
-                d.mu[grow * 16 + a] = mean;
-                d.ls[grow * 16 + a] = lstd;
-                d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
-                d.z[grow * 16 + a] = zz;
-                d.anew[grow * 16 + a] = act;
-                d.epsv[grow * 16 + a] = eps;
-            } else if (pass == 4) {
-                d.a2[grow * 16 + a] = act;
-            }
-        } else if (pass == 2) {
-            d.anew[grow * 16 + a] = 0.f;
-        } else if (pass == 4) {
-            d.a2[grow * 16 + a] = 0.f;
-        }
-        STAMP(0, 14);
-        const float lsum = group16_sum(lp);
-        if (owner && a == 0) (next ? d.logpi2 : d.logpi)[grow] = lsum;
-        if (pass == 2 && a == 0) red[row] = lsum;
-        lds_barrier();
-        if (pass == 2 && threadIdx.x == 0) {
-            // block partial of sum(log_pi) in a fixed order, then the arrival ticket
-            float s = 0.f;
-            for (int i = 0; i < RB; ++i) s += red[i];
-            __hip_atomic_store(&d.part_logpi[rb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            Ctl *cc = d.ctl;
-            const unsigned tk = __hip_atomic_fetch_add(&cc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk == (unsigned)(d.NB - 1)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                cc->ticket = 0u;
-                const double tt = (double)sa.adam_t;
-                const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
-                cc->bc1 = bc1;
-                cc->bc2s = sqrt(bc2);
-                if (d.auto_alpha) {
-                    float sum = 0.f;
-                    for (int i = 0; i < d.NB; ++i)
-                        sum += __hip_atomic_load(&d.part_logpi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const float mean_lp = sum / (float)B + d.target_entropy;     // mean(log_pi + H)
-                    const float la = cc->log_alpha;
-                    // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0 => log_alpha == 0 logs -0.0
-                    cc->alpha_loss = -((la * mean_lp) + 0.0f);
-                    const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
-                    const float m = cc->a_m + (1.0f - ADAM_B1) * (gr - cc->a_m);
-                    const float v = cc->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
-                    const float step_size = (float)((double)d.alpha_lr / bc1);
-                    const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
-                    const float nla = la + (-step_size * m) / denom;
-                    cc->a_m = m; cc->a_v = v; cc->log_alpha = nla;
-                    cc->alpha = expf(nla);
-                } else {
-                    cc->alpha = 1.0f;
-                    cc->alpha_loss = 0.0f;
-                }
-            }
-        }
+    for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
+    SB();
+    WRing<1, RDH4> r1;
+    r1.init(P + L1.offW, H, n0, 16);
+    r1.fill(H >> 4);
+    const float bv1 = P[L1.offB + n0 + c];
+    WRing<NTH, 1> rh;                                        // pi: head rows x this wave's 16 columns
+    float w3[4] = {0.f, 0.f, 0.f, 0.f};
+    if (is_pi) {
+        rh.init(P + L2.offW, H, 0, 16, 4 * part + wave);
+        rh.fill(1);
     } else {
-        issue_q_first();
-        SB();
-        issue_q_second();
-        SB();
-        rows.commit(XQ, KLQ, d.KQ);
-        lds_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w3[u] = P[L2.offW + 64 * part + p16 + 16 * u];
     }
-
-    // ---- Q / target-Q net on cat(obs, action) ----
-    STAMP(0, 4);
-    float *h1T = (pass < 4) ? d.QH1T + (size_t)pass * H * B : nullptr;
-    float *h2T = (pass < 4) ? d.QH2T + (size_t)pass * H * B : nullptr;
-    {
+    SB();
+    rows.commit(X0, KL0, K0);
+    lds_barrier();
+    {   // first layer, all 256 features (recomputed by the four blocks of this row-block)
         f32x4 acc[4] = {};
-        gemm_first(XQ, KLQ, d.KQ >> 4, acc);
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, h1T, B, row0);
+        if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
+        else gemm_straight(r0, X0, KL0, K0 >> 4, acc);
+        float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
     }
     lds_barrier();
-    STAMP(0, 5);
-    {
-        f32x4 acc[4] = {};
+    {   // this block's 64 columns of the 256x256 layer
+        f32x4 acc[1] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
-        STAMP(0, 6);
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv1, X2, H, h2T, B, row0);
+        float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
+        slice_epilogue(acc[0], bv1, wave, XS, h2T ? h2T + (size_t)(n0 + c) * B : nullptr, row0);
     }
     lds_barrier();
-    // last_fc: q[row] = h2[row] . w3 + b3   (N = 1: VALU dot, 16 lanes per row)
+    if (is_pi) {
+        // partial head pre-activations over these 64 columns (each wave contracts its own 16)
+        f32x4 acc[NTH] = {};
+        gemm_ring(rh, XS, 64, 1, acc, wave);
+        splitk_reduce<NTH>(acc, nullptr, red, d.headpart + ((size_t)(sq * NB + rb) * SPLIT + part) * (RB * 32), 32);
+    } else {
+        // partial q over these 64 columns
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += XS[lds_off(row, p16 + 16 * u, 64)] * w3[u];
+        s = group16_sum(s);
+        if (p16 == 0) d.qpart[((size_t)sq * SPLIT + part) * B + row0 + row] = s;
+    }
+}
+
+template <int NTH, bool WIDE>
+__global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int B = d.B, O = d.O, A = d.A, NB = d.NB;
+    const int KLQ = (d.KQ + 63) & ~63;
+    float *XQ = lds;                     // [16][KLQ]  cat(obs, action)
+    float *X1 = XQ + RB * KLQ;           // [16][256]
+    float *XS = X1 + RB * H;             // [16][64]
+    float *red = XS + RB * 64;           // 64 floats
+    const int b = blockIdx.x;
+    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, p4 = (b >> 2) / NB;   // p4: Q1, Q2 (s,a_new); T1, T2 (s',a')
+    const int side = p4 >> 1, pass = 2 + p4;
+    const int row0 = rb * RB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
+    const int row = threadIdx.x >> 4, a = threadIdx.x & 15, grow = row0 + row;
+    const float *PQ = d.P[(p4 < 2) ? 1 + p4 : 1 + p4];       // nets 1,2 (Q1,Q2) and 3,4 (T1,T2)
+    const int n0 = 64 * part + 16 * wave;
+    const bool own_s = (p4 == 0) && (part == 0), own_n = (p4 == 2) && (part == 0);
+
+    // ---- requests, in consumption order ----
+    float hm[SPLIT], hr[SPLIT], hbm = 0.f, hbr = 0.f, epsin = 0.f;
+    const float *epp = side ? d.eps2 : d.eps1;
+    {
+        const float *hp = d.headpart + (size_t)(side * NB + rb) * SPLIT * (RB * 32) + row * 32;
+        const int am = (a < A) ? a : 0;
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) { hm[p] = hp[p * (RB * 32) + am]; hr[p] = hp[p * (RB * 32) + A + am]; }
+        hbm = d.P[0][d.LP[2].offB + am];
+        hbr = d.P[0][d.LP[2].offB + A + am];
+        if (epp) epsin = epp[grow * A + am];
+    }
+    RowRegs<WIDE ? 32 : 8> rows;
+    rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
+    WRing<4, WIDE ? RD : RD0> r0;
+    r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
+    r0.fill(d.KQ >> 4);
+    float bv0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    SB();
+    WRing<1, RDH4> r1;
+    r1.init(PQ + d.LQ[1].offW, H, n0, 16);
+    r1.fill(H >> 4);
+    const float bv1 = PQ[d.LQ[1].offB + n0 + c];
+    float w3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[u] = PQ[d.LQ[2].offW + 64 * part + a + 16 * u];
+    SB();
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
+    USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
+    rows.commit(XQ, KLQ, d.KQ, O, O + A);
+    // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
+    float lp = 0.f;
+    if (a < A) {
+        const float mean = (((hm[0] + hm[1]) + hm[2]) + hm[3]) + hbm;
+        const float raw = (((hr[0] + hr[1]) + hr[2]) + hr[3]) + hbr;
+        const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float stdv = expf(lstd);
+        const float eps = epp ? epsin
+                              : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a),
+                                              side ? 1u : 0u);
+        const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
+        const float act = tanhf(zz);
+        const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
+        const float var = __fmul_rn(stdv, stdv);
+        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+        lp = nlp - logf(1.0f - act * act + TANH_EPS);
+        XQ[lds_off(row, O + a, KLQ)] = act;
+        if (own_s) {
+            d.mu[grow * 16 + a] = mean;
+            d.ls[grow * 16 + a] = lstd;
+            d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
+            d.z[grow * 16 + a] = zz;
+            d.anew[grow * 16 + a] = act;
+            d.epsv[grow * 16 + a] = eps;
+        } else if (own_n) {
+            d.a2[grow * 16 + a] = act;
+        }
+    } else if (own_s) {
+        d.anew[grow * 16 + a] = 0.f;
+    } else if (own_n) {
+        d.a2[grow * 16 + a] = 0.f;
+    }
+    const float lsum = group16_sum(lp);
+    if ((own_s || own_n) && a == 0) (side ? d.logpi2 : d.logpi)[grow] = lsum;
+    if (own_s && a == 0) red[row] = lsum;
+    lds_barrier();
+    if (own_s && threadIdx.x == 0) {
+        // block partial of sum(log_pi) in a fixed order, then the arrival ticket: the last of the NB
+        // owner blocks does the alpha Adam step (SURVEY Appendix A lines 4-6) and publishes this step's
+        // Adam bias corrections.  Release / acquire at agent scope, no spinning.
+        float s = 0.f;
+        for (int i = 0; i < RB; ++i) s += red[i];
+        __hip_atomic_store(&d.part_logpi[rb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Ctl *cc = d.ctl;
+        const unsigned tk = __hip_atomic_fetch_add(&cc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)(NB - 1)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            cc->ticket = 0u;
+            const double tt = (double)sa.adam_t;
+            const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
+            cc->bc1 = bc1;
+            cc->bc2s = sqrt(bc2);
+            if (d.auto_alpha) {
+                float sum = 0.f;
+                for (int i = 0; i < NB; ++i)
+                    sum += __hip_atomic_load(&d.part_logpi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float mean_lp = sum / (float)B + d.target_entropy;     // mean(log_pi + H)
+                const float la = cc->log_alpha;
+                // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0 => log_alpha == 0 logs -0.0
+                cc->alpha_loss = -((la * mean_lp) + 0.0f);
+                const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
+                const float m = cc->a_m + (1.0f - ADAM_B1) * (gr - cc->a_m);
+                const float v = cc->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
+                const float step_size = (float)((double)d.alpha_lr / bc1);
+                const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
+                const float nla = la + (-step_size * m) / denom;
+                cc->a_m = m; cc->a_v = v; cc->log_alpha = nla;
+                cc->alpha = expf(nla);
+            } else {
+                cc->alpha = 1.0f;
+                cc->alpha_loss = 0.0f;
+            }
+        }
+    }
+    // ---- Q / target-Q net on cat(obs, action) ----
+    {
+        f32x4 acc[4] = {};
+        if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, d.KQ >> 4, acc);
+        else gemm_straight(r0, XQ, KLQ, d.KQ >> 4, acc);
+        float *h1T = (p4 < 2) ? d.QH1T + (size_t)pass * H * B : nullptr;
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
+    }
+    lds_barrier();
+    {
+        f32x4 acc[1] = {};
+        gemm_ring(r1, X1, H, H >> 4, acc);
+        float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
+        slice_epilogue(acc[0], bv1, wave, XS, h2T ? h2T + (size_t)(n0 + c) * B : nullptr, row0);
+    }
+    lds_barrier();
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) s += X2[lds_off(row, part + 16 * u, H)] * w3[u];
+    for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, 64)] * w3[u];
     s = group16_sum(s);
-    if (part == 0) d.q[(size_t)pass * B + row0 + row] = s + b3;
-    STAMP(0, 7);
+    if (a == 0) d.qpart[((size_t)pass * SPLIT + part) * B + grow] = s;
 }
 
 // ------------------------------------------------------------------------------------------
-// K3: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through
-// Q1/Q2 down to d/da_new (input gradient only).
+// C: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through Q1/Q2
+// down to d/da_new (input gradient only; partial over this block's 64 first-layer features).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int B = d.B;
-    float *X2 = lds;                 // dL/dh2 row-block [16][256]
-    float *X1 = X2 + RB * H;         // dL/dh1 row-block (actor)
-    float *red = X1 + RB * H;        // 1024 floats
+    const int B = d.B, NB = d.NB;
+    float *X2 = lds;                 // dL/dh2 row-block [16][256] (recomputed by the four blocks)
+    float *XS = X2 + RB * H;         // dL/dh1, this block's 64 features [16][64] (actor)
+    float *red = XS + RB * 64;       // 1024 floats
     __shared__ float s_dq[RB];
-    const int pass = blockIdx.x / d.NB, rb = blockIdx.x - pass * d.NB;
+    const int b = blockIdx.x;
+    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, pass = (b >> 2) / NB;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const bool critic = pass < 2;
@@ -603,59 +646,73 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     const float invB = 1.0f / (float)B;
     const float *h2T = d.QH2T + (size_t)pass * H * B;
     const float *h1T = d.QH1T + (size_t)pass * H * B;
+    const int n0 = 64 * part + 16 * wave;
+    const long long oB3 = d.LQ[2].offB;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const float alpha = sload(&d.ctl->alpha);
-    float in_a = 0.f, in_b = 0.f, in_c = 0.f, in_r = 0.f, in_t = 0.f, in_q = 0.f;   // loads only: no use before SB
+    const float b3a = sload(d.P[critic ? 3 : 1] + oB3), b3b = sload(d.P[critic ? 4 : 2] + oB3), b3q = sload(P + oB3);
+    float qa[SPLIT], qb[SPLIT], qq[SPLIT], in_c = 0.f, in_r = 0.f, in_t = 0.f;      // loads only: no use before SB
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
-        if (critic) {
-            in_a = d.q[4 * (size_t)B + r]; in_b = d.q[5 * (size_t)B + r]; in_c = d.logpi2[r];
-            in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
-            in_q = d.q[(size_t)qi * B + r];
-        } else {
-            in_a = d.q[(size_t)(2 + qi) * B + r]; in_b = d.q[(size_t)(3 - qi) * B + r];
+        const int pa = critic ? 4 : 2, pb = critic ? 5 : 3;
+#pragma unroll
+        for (int p = 0; p < SPLIT; ++p) {
+            qa[p] = d.qpart[((size_t)pa * SPLIT + p) * B + r];
+            qb[p] = d.qpart[((size_t)pb * SPLIT + p) * B + r];
+            if (critic) qq[p] = d.qpart[((size_t)qi * SPLIT + p) * B + r];
         }
+        if (critic) { in_c = d.logpi2[r]; in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r]; }
     }
     const int k = threadIdx.x;
     const float wk = P[d.LQ[2].offW + k];
-    f32x4 h2v[4], h1v[4];
+    f32x4 h2v[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
     SB();
-    WRing<4, RDH4> r1;
-    r1.init(PT + d.LQ[1].offWt, H, 64 * wave, 16);
-    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    WRing<1, RDH4> r1;
+    r1.init(PT + d.LQ[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) h1v[t] = ld4(h1T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
-    WRing<1> ra;
+    const f32x4 h1v = ld4(h1T + (size_t)(n0 + c) * B + row0 + 4 * g);
+    WRing<1, 1> ra;
     if (!critic) {
-        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * wave);
-        ra.fill(4);
+        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * part + wave);
+        ra.fill(1);
     }
     SB();
-    USE_FROM_HERE(in_a); USE_FROM_HERE(in_b); USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t); USE_FROM_HERE(in_q);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
+    USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
+        const float va = (((qa[0] + qa[1]) + qa[2]) + qa[3]) + b3a;      // T1 (critic) / Q1(s,a_new) (actor)
+        const float vb = (((qb[0] + qb[1]) + qb[2]) + qb[3]) + b3b;      // T2          / Q2(s,a_new)
         float dq;
         if (critic) {
-            const float tq = fminf(in_a, in_b) - alpha * in_c;
+            const float vq = (((qq[0] + qq[1]) + qq[2]) + qq[3]) + b3q;  // Q_i(s,a)
+            const float tq = fminf(va, vb) - alpha * in_c;
             const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
-            if (qi == 0) d.y[r] = yv;
-            dq = 2.0f * (in_q - yv) * invB;
-            d.dq16T[(size_t)qi * 16 * B + r] = dq;                  // row 0 of the padded [16][B]
+            dq = 2.0f * (vq - yv) * invB;
+            if (part == 0) {
+                d.q[(size_t)qi * B + r] = vq;
+                d.dq16T[(size_t)qi * 16 * B + r] = dq;                  // row 0 of the padded [16][B]
+                if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
+            }
         } else {
-            const float sel = (in_a < in_b) ? 1.0f : ((in_a == in_b) ? 0.5f : 0.0f);   // torch.min backward
+            const float mine = qi ? vb : va, other = qi ? va : vb;
+            const float sel = (mine < other) ? 1.0f : ((mine == other) ? 0.5f : 0.0f);   // torch.min backward
             dq = -invB * sel;
+            if (part == 0 && qi == 0) { d.q[2 * (size_t)B + r] = va; d.q[3 * (size_t)B + r] = vb; }
         }
         s_dq[threadIdx.x] = dq;
     }
     lds_barrier();
-    // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups)
+    // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner quarter
     {
-        float *outT = critic ? d.dQH2T + (size_t)qi * H * B : nullptr;
+        float *outT = (critic && (k >> 6) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             f32x4 gv;
@@ -668,36 +725,30 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         }
     }
     lds_barrier();
-    // dL/dh1 = (dL/dh2 . W2) * relu'(h1)
+    // dL/dh1[:, 64 features] = (dL/dh2 . W2)[:, slice] * relu'(h1)
     {
-        f32x4 acc[4] = {};
+        f32x4 acc[1] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
-        float *outT = critic ? d.dQH1T + (size_t)qi * H * B : nullptr;
+        f32x4 gv;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = 64 * wave + 16 * t + c;
-            f32x4 gv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
-                if (!critic) X1[lds_off(4 * g + i, n, H)] = gv[i];
-            }
-            if (outT) st4(outT + (size_t)n * B + row0 + 4 * g, gv);
+        for (int i = 0; i < 4; ++i) {
+            gv[i] = (h1v[i] > 0.f) ? acc[0][i] : 0.f;
+            if (!critic) XS[lds_off(4 * g + i, 16 * wave + c, 64)] = gv[i];
         }
+        if (critic) st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + c) * B + row0 + 4 * g, gv);
     }
     if (critic) return;
     lds_barrier();
-    // d/da_new = dL/dh1 . W1[:, O:O+A]   -> da[qi][row][16]
+    // partial d/da_new = dL/dh1[:, slice] . W1[slice, O:O+A]   -> dapart[qi][part][row][16]
     {
         f32x4 acc[1] = {};
-        gemm_ring(ra, X1, H, 4, acc, 4 * wave);
-        splitk_reduce<1>(acc, nullptr, red, X2, 16);
+        gemm_ring(ra, XS, 64, 1, acc, wave);
+        splitk_reduce<1>(acc, nullptr, red, d.dapart + (((size_t)qi * SPLIT + part) * B + row0) * 16, 16);
     }
-    d.da[(size_t)qi * B * 16 + (size_t)row0 * 16 + threadIdx.x] = X2[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient.
+// D: policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient.
 //   dL/dz      = da*(1-a^2) + (alpha/B) * 2a(1-a^2)/(1-a^2+1e-6)
 //   dL/dmu     = dL/dz                      (the Normal terms cancel exactly under rsample)
 //   dL/dlogstd = dL/dz * std*eps - alpha/B  (masked by the clamp)
@@ -707,69 +758,63 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, A = d.A;
     float *XH = lds;                 // [16][64] head gradient row-block
-    float *X2 = XH + RB * 64;        // [16][256]
-    const int rb = blockIdx.x, row0 = rb * RB;
+    float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the four blocks)
+    const int part = blockIdx.x & (SPLIT - 1), rb = blockIdx.x >> 2, row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const float *PT = d.PT[0];
     const float invB = 1.0f / (float)B;
+    const int n0 = 64 * part + 16 * wave;
 
-#ifdef SAC_EXPERIMENT_PRETOUCH
-    {   // timing experiment: pull the whole W1^T through this XCD's L2 first (results unchanged)
-        const float *Wp = PT + d.LP[1].offWt;
-        f32x4 sink = {0.f, 0.f, 0.f, 0.f};
-        for (int e = threadIdx.x; e < H * H / 4; e += 256) sink += ld4(Wp + 4 * e);
-        if (sink[0] == 12345.678f) d.dheadT[0] = sink[1];
-        lds_barrier();
-    }
-#endif
-    STAMP(3, 0);
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const float alpha = sload(&d.ctl->alpha);
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int gi = (row0 + row) * 16 + a;
-    float act = 0.f, da1 = 0.f, da2 = 0.f, lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
+    float act = 0.f, dap[2 * SPLIT], lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
+#pragma unroll
+    for (int p = 0; p < 2 * SPLIT; ++p) dap[p] = 0.f;
     if (a < A) {
         act = d.anew[gi];
-        da1 = d.da[gi]; da2 = d.da[(size_t)B * 16 + gi];
+#pragma unroll
+        for (int p = 0; p < 2 * SPLIT; ++p) dap[p] = d.dapart[(size_t)p * B * 16 + gi];
         lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
     }
     SB();
     WRing<4> rh;
-    WRing<4, RDH4> r1;
     rh.init(PT + d.LP[2].offWt, d.LP[2].Np, 64 * wave, 16);
     rh.fill(NTH);
-    f32x4 h2v[4], h1v[4];
+    f32x4 h2v[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
     SB();
-    r1.init(PT + d.LP[1].offWt, H, 64 * wave, 16);
-    r1.rotate(SAC_ROT(blockIdx.x), H >> 4);
+    WRing<1, RDH4> r1;
+    r1.init(PT + d.LP[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) h1v[t] = ld4(d.PH1T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
+    const f32x4 h1v = ld4(d.PH1T + (size_t)(n0 + c) * B + row0 + 4 * g);
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
     lds_barrier();
-    STAMP(3, 1);
-    USE_FROM_HERE(act); USE_FROM_HERE(da1); USE_FROM_HERE(da2); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
+    USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
+#pragma unroll
+    for (int p = 0; p < 2 * SPLIT; ++p) USE_FROM_HERE(dap[p]);
     if (a < A) {
+        const float da1 = ((dap[0] + dap[1]) + dap[2]) + dap[3], da2 = ((dap[4] + dap[5]) + dap[6]) + dap[7];
         const float om = 1.0f - act * act;
         const float dz = (da1 + da2) * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
         const float stdv = expf(lsv);
         const float dls = (dz * stdv * epv - alpha * invB) * okv;
         XH[lds_off(row, a, 64)] = dz;
         XH[lds_off(row, A + a, 64)] = dls;
-        d.dheadT[(size_t)a * B + row0 + row] = dz;
-        d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+        if (part == 0) {
+            d.dheadT[(size_t)a * B + row0 + row] = dz;
+            d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+        }
     }
     lds_barrier();
-    STAMP(3, 2);
     {
         f32x4 acc[4] = {};
         gemm_ring(rh, XH, 64, NTH, acc);
-        STAMP(3, 3);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = 64 * wave + 16 * t + c;
@@ -779,25 +824,18 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
                 gv[i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
                 X2[lds_off(4 * g + i, n, H)] = gv[i];
             }
-            st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
+            if (wave == part) st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
     lds_barrier();
-    STAMP(3, 4);
     {
-        f32x4 acc[4] = {};
+        f32x4 acc[1] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
-        STAMP(3, 5);
+        f32x4 gv;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int n = 64 * wave + 16 * t + c;
-            f32x4 gv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
-            st4(d.dPH1T + (size_t)n * B + row0 + 4 * g, gv);
-        }
+        for (int i = 0; i < 4; ++i) gv[i] = (h1v[i] > 0.f) ? acc[0][i] : 0.f;
+        st4(d.dPH1T + (size_t)(n0 + c) * B + row0 + 4 * g, gv);
     }
-    STAMP(3, 6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1060,8 +1098,10 @@ struct sac_trainer {
     float last_ms[4] = {0, 0, 0, 0};
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
-    size_t lds_pf = 0, lds_qf = 0, lds_qb = 0, lds_pb = 0;
-    void (*fwd_kernel)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    size_t lds_qb = 0, lds_pb = 0;
+    void (*fwd_a)(Dev, const float *, SlotLayout) = nullptr;
+    void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    size_t lds_fa = 0, lds_fb = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
 };
 
@@ -1159,15 +1199,17 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     const int NB = t->NB;
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0};
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(t->fwd_kernel, dim3(6 * NB), dim3(256), t->lds_pf, s, d, S, SL, sa);
+    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPLIT * NB), dim3(256), t->lds_fa, s, d, S, SL);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * NB), dim3(256), t->lds_qb, s, d, S, SL);
+    hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPLIT * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(NB), dim3(256), t->lds_pb, s, d);
-    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(NB), dim3(256), t->lds_pb, s, d);
+    hipLaunchKernelGGL(k_q_bwd, dim3(4 * SPLIT * NB), dim3(256), t->lds_qb, s, d, S, SL);
     if (ev) SAC_HIP(hipEventRecord(ev[3], s));
+    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d);
+    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d);
+    if (ev) SAC_HIP(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
-    if (ev) { SAC_HIP(hipEventRecord(ev[4], s)); SAC_HIP(hipEventRecord(ev[5], s)); }
+    if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
     SAC_HIP(hipGetLastError());
     t->n_train_steps_total += 1;
     t->adam_t += 1;
@@ -1233,7 +1275,8 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
         {&d.mu, 16LL * B}, {&d.ls, 16LL * B}, {&d.lsok, 16LL * B}, {&d.z, 16LL * B}, {&d.anew, 16LL * B},
         {&d.epsv, 16LL * B}, {&d.logpi, B}, {&d.a2, 16LL * B}, {&d.logpi2, B}, {&d.part_logpi, round_up(t->NB, 64)},
         {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B},
-        {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B}, {&d.da, 2LL * 16 * B},
+        {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
+        {&d.headpart, 2LL * t->NB * SPLIT * RB * 32}, {&d.qpart, 6LL * SPLIT * B}, {&d.dapart, 2LL * SPLIT * B * 16},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
     long long tot = 0;
     for (auto &p : parts) tot += round_up64(p.second, 64);
@@ -1300,17 +1343,23 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
 
     const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
-    t->lds_pf = sizeof(float) * (size_t)(RB * KL0p + RB * KL0q + 2 * RB * H + RB * 32 + 4 * nth * 256);
-    t->lds_qf = 0;
-    t->lds_qb = sizeof(float) * (size_t)(2 * RB * H + 1024);
+    (void)KL0p;
+    t->lds_fa = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + 4 * nth * 256);
+    t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + 64);
+    t->lds_qb = sizeof(float) * (size_t)(RB * H + RB * 64 + 1024);
     t->lds_pb = sizeof(float) * (size_t)(RB * 64 + RB * H);
-    SAC_REQUIRE(t->lds_pf <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
+    SAC_REQUIRE(t->lds_fa <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     const bool wide = t->KQ > 16 * RD0;
-    t->fwd_kernel = (nth == 1) ? (wide ? &k_fwd<1, true> : &k_fwd<1, false>)
-                               : (wide ? &k_fwd<2, true> : &k_fwd<2, false>);
-    if (t->lds_pf > 64 * 1024)
-        SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_pf));
+    t->fwd_a = (nth == 1) ? (wide ? &k_fwd_a<1, true> : &k_fwd_a<1, false>)
+                          : (wide ? &k_fwd_a<2, true> : &k_fwd_a<2, false>);
+    t->fwd_b = (nth == 1) ? (wide ? &k_fwd_b<1, true> : &k_fwd_b<1, false>)
+                          : (wide ? &k_fwd_b<2, true> : &k_fwd_b<2, false>);
+    if (t->lds_fa > 64 * 1024) {
+        SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fa));
+        SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_b),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fb));
+    }
     SAC_HIP(hipStreamSynchronize(s));
     *out = t;
     return 0;
@@ -1520,14 +1569,14 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     return 0;
 }
 
-int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[8]) {
+int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[9]) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
     SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
     if (stage_batches(t, b, n_steps)) return -1;
-    constexpr int NE = 6;            // e0 K1 e1 K2 e2 K3 e3 K4 e4 (nothing) e5
+    constexpr int NE = 7;            // e0 A e1 B e2 C e3 D e4 E e5 (nothing) e6
     std::vector<hipEvent_t> ev((size_t)n_steps * NE);
     for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
     for (int64_t i = 0; i < n_steps; ++i)
@@ -1535,7 +1584,7 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     SAC_HIP(hipStreamSynchronize(s));
     // interval k = launch k between two event records; the empty interval e4->e5 measures what an
     // event pair costs by itself and is subtracted from the four kernel intervals
-    double acc[NE - 1] = {0, 0, 0, 0, 0};
+    double acc[NE - 1] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = 0; i < n_steps; ++i)
         for (int k = 0; k < NE - 1; ++k) {
             float ms = 0.f;
@@ -1548,12 +1597,12 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     SAC_HIP(hipEventElapsedTime(&out_ms[0], b->ev[0], b->ev[1]));
     SAC_HIP(hipEventElapsedTime(&out_ms[1], b->ev[1], b->ev[2]));
     const double empty = acc[NE - 2] / (double)n_steps;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         const double v = acc[k] / (double)n_steps - empty;
         out_ms[2 + k] = (float)(v > 0 ? v : 0);
     }
-    out_ms[6] = (float)empty;
-    out_ms[7] = tot;
+    out_ms[7] = (float)empty;
+    out_ms[8] = tot;
     t->mirror_valid = false;
     return 0;
 }

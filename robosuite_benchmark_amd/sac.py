@@ -146,13 +146,13 @@ class SACTrainer:
         B = int(batch_size or self._batch)
         if self._h is None or B != self._batch:
             self._create(B)
-        ms = np.zeros(8, np.float32)
+        ms = np.zeros(9, np.float32)
         _lib.check(self._lib.sac_profile_loop(self._h, replay_buffer._h, int(n_steps), _lib.ptr(ms)),
                    "sac_profile_loop")
         self._num_train_steps += int(n_steps)
         self._host_policy_stale = True
-        names = ["k_mt_randint", "k_gather", "k_fwd", "k_q_bwd", "k_policy_bwd", "k_dw_adam", "event_pair",
-                 "steps_wall"]
+        names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_q_bwd", "k_policy_bwd", "k_dw_adam",
+                 "event_pair", "steps_wall"]
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
     def loop_timing_ms(self):
