@@ -36,6 +36,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int H = 256;            // hidden width (every shipped variant.json)
 constexpr float LOG_SIG_MAX = 2.0f, LOG_SIG_MIN = -20.0f, TANH_EPS = 1e-6f;
 constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
+// torch computes 1 - beta in double and applies it as an fp32 scalar: (float)(1.0 - 0.9), (float)(1.0 - 0.999)
+constexpr float ADAM_1MB1 = (float)(1.0 - 0.9), ADAM_1MB2 = (float)(1.0 - 0.999);
 constexpr int DIAG_TRACE_CAP = 4096;
 constexpr int RD = 4;             // ring depth (k-chunks in flight) for the runtime-K first layers
 #ifndef SAC_RDH
@@ -52,14 +54,15 @@ struct StepArg {
     long long adam_t;              // optimizer step count of this step (1-based)
     int loop_pos;                  // index of this step inside the current sac_train_loop
     int pad;
+    double bc1, bc2s;              // 1 - beta1^t and sqrt(1 - beta2^t), computed on the host in double like torch
 };
 
-struct Ctl {                       // device-resident state: entropy coefficient + this step's Adam scalars
+struct Ctl {                       // device-resident state of the entropy coefficient (Adam on log_alpha)
     float log_alpha, a_m, a_v, alpha, alpha_loss;
-    unsigned ticket;               // arrival counter of the forward kernel's owner blocks
-    int pad[1];
-    double bc1, bc2s;              // 1 - beta1^t, sqrt(1 - beta2^t) of the CURRENT step (K2 writes)
+    int pad[3];
 };
+
+struct AlphaStep { float alpha, alpha_loss, log_alpha, m, v; };
 
 struct Layer {                     // one nn.Linear in the padded device layout
     int N, K, Np, Kp;
@@ -158,6 +161,31 @@ __device__ __forceinline__ T sload(const T *p) {
     return *(const __attribute__((address_space(4))) T *)(uintptr_t)p;
 }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// SURVEY Appendix A lines 4-6: alpha_loss = -mean(log_alpha * (log_pi + H)); one Adam step on log_alpha;
+// alpha = exp(log_alpha) (post-step).  sum(log_pi) arrives as NB per-row-block partials (written by the
+// previous launch); every workgroup that needs alpha recomputes this handful of scalar operations from the
+// same inputs in the same order -- bit-identical everywhere, no reduction kernel, no in-launch hand-off.
+// The new state is stored once, by the diagnostics block of the last launch of the step.
+__device__ __forceinline__ AlphaStep alpha_step(const Ctl *ctl, const float *part_logpi, int NB, int B, float target_entropy,
+                                                float lr, int auto_alpha, double bc1, double bc2s) {
+    AlphaStep r;
+    const float la = sload(&ctl->log_alpha), m0 = sload(&ctl->a_m), v0 = sload(&ctl->a_v);
+    if (!auto_alpha) { r.alpha = 1.0f; r.alpha_loss = 0.0f; r.log_alpha = la; r.m = m0; r.v = v0; return r; }
+    float sum = 0.f;
+    for (int i = 0; i < NB; ++i) sum += sload(part_logpi + i);
+    const float mean_lp = sum / (float)B + target_entropy;               // mean(log_pi + H)
+    // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0 => log_alpha == 0 logs -0.0
+    r.alpha_loss = -((la * mean_lp) + 0.0f);
+    const float gr = -mean_lp;                                           // d alpha_loss / d log_alpha
+    r.m = m0 + ADAM_1MB1 * (gr - m0);
+    r.v = v0 * ADAM_B2 + ADAM_1MB2 * gr * gr;
+    const float step_size = (float)((double)lr / bc1);
+    const float denom = sqrtf(r.v) / (float)bc2s + 1e-8f;
+    r.log_alpha = la + (-step_size * r.m) / denom;
+    r.alpha = expf(r.log_alpha);
+    return r;
+}
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
 // Weight stream of one wave: NT column tiles of 16 outputs, k-chunks of 16 held in a D-deep
@@ -380,6 +408,8 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 //   E k_dw_adam              (below)
 // ------------------------------------------------------------------------------------------
 constexpr int SPLIT = 4;
+constexpr int RDS = 8;            // ring depth of a 64-column slice (one tile per wave): 8 k-chunks = 8 KB per wave in
+                                  // flight; measured 4: -1 %, 8: best, 16 (whole sweep up front): -7 %
 
 // relu(acc + bias) of this wave's single tile -> local slice buffer XS[16][64] and (optionally) the
 // feature-major global row of that feature
@@ -427,7 +457,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
     SB();
-    WRing<1, RDH4> r1;
+    WRing<1, RDS> r1;
     r1.init(P + L1.offW, H, n0, 16);
     r1.fill(H >> 4);
     const float bv1 = P[L1.offB + n0 + c];
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
     SB();
-    WRing<1, RDH4> r1;
+    WRing<1, RDS> r1;
     r1.init(PQ + d.LQ[1].offW, H, n0, 16);
     r1.fill(H >> 4);
     const float bv1 = PQ[d.LQ[1].offB + n0 + c];
@@ -561,45 +591,10 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     if ((own_s || own_n) && a == 0) (side ? d.logpi2 : d.logpi)[grow] = lsum;
     if (own_s && a == 0) red[row] = lsum;
     lds_barrier();
-    if (own_s && threadIdx.x == 0) {
-        // block partial of sum(log_pi) in a fixed order, then the arrival ticket: the last of the NB
-        // owner blocks does the alpha Adam step (SURVEY Appendix A lines 4-6) and publishes this step's
-        // Adam bias corrections.  Release / acquire at agent scope, no spinning.
+    if (own_s && threadIdx.x == 0) {          // this row-block's sum(log_pi), fixed order
         float s = 0.f;
         for (int i = 0; i < RB; ++i) s += red[i];
-        __hip_atomic_store(&d.part_logpi[rb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        Ctl *cc = d.ctl;
-        const unsigned tk = __hip_atomic_fetch_add(&cc->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == (unsigned)(NB - 1)) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            cc->ticket = 0u;
-            const double tt = (double)sa.adam_t;
-            const double bc1 = 1.0 - pow((double)ADAM_B1, tt), bc2 = 1.0 - pow((double)ADAM_B2, tt);
-            cc->bc1 = bc1;
-            cc->bc2s = sqrt(bc2);
-            if (d.auto_alpha) {
-                float sum = 0.f;
-                for (int i = 0; i < NB; ++i)
-                    sum += __hip_atomic_load(&d.part_logpi[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float mean_lp = sum / (float)B + d.target_entropy;     // mean(log_pi + H)
-                const float la = cc->log_alpha;
-                // torch: -(log_alpha * x).mean(); the mean's running sum starts at +0 => log_alpha == 0 logs -0.0
-                cc->alpha_loss = -((la * mean_lp) + 0.0f);
-                const float gr = -mean_lp;                                   // d alpha_loss / d log_alpha
-                const float m = cc->a_m + (1.0f - ADAM_B1) * (gr - cc->a_m);
-                const float v = cc->a_v * ADAM_B2 + (1.0f - ADAM_B2) * gr * gr;
-                const float step_size = (float)((double)d.alpha_lr / bc1);
-                const float denom = sqrtf(v) / (float)sqrt(bc2) + ADAM_EPS;
-                const float nla = la + (-step_size * m) / denom;
-                cc->a_m = m; cc->a_v = v; cc->log_alpha = nla;
-                cc->alpha = expf(nla);
-            } else {
-                cc->alpha = 1.0f;
-                cc->alpha_loss = 0.0f;
-            }
-        }
+        d.part_logpi[rb] = s;
     }
     // ---- Q / target-Q net on cat(obs, action) ----
     {
@@ -628,7 +623,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
 // C: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through Q1/Q2
 // down to d/da_new (input gradient only; partial over this block's 64 first-layer features).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL) {
+__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, NB = d.NB;
     float *X2 = lds;                 // dL/dh2 row-block [16][256] (recomputed by the four blocks)
@@ -650,7 +645,6 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     const long long oB3 = d.LQ[2].offB;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
-    const float alpha = sload(&d.ctl->alpha);
     const float b3a = sload(d.P[critic ? 3 : 1] + oB3), b3b = sload(d.P[critic ? 4 : 2] + oB3), b3q = sload(P + oB3);
     float qa[SPLIT], qb[SPLIT], qq[SPLIT], in_c = 0.f, in_r = 0.f, in_t = 0.f;      // loads only: no use before SB
 #pragma unroll
@@ -672,7 +666,7 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
     SB();
-    WRing<1, RDH4> r1;
+    WRing<1, RDS> r1;
     r1.init(PT + d.LQ[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
@@ -683,6 +677,8 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         ra.fill(1);
     }
     SB();
+    // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
+    const float alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
 #pragma unroll
     for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
@@ -754,7 +750,7 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
 //   dL/dlogstd = dL/dz * std*eps - alpha/B  (masked by the clamp)
 // ------------------------------------------------------------------------------------------
 template <int NTH>
-__global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
+__global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, A = d.A;
     float *XH = lds;                 // [16][64] head gradient row-block
@@ -767,7 +763,6 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
     const int n0 = 64 * part + 16 * wave;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
-    const float alpha = sload(&d.ctl->alpha);
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int gi = (row0 + row) * 16 + a;
     float act = 0.f, dap[2 * SPLIT], lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
@@ -787,13 +782,14 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
     SB();
-    WRing<1, RDH4> r1;
+    WRing<1, RDS> r1;
     r1.init(PT + d.LP[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
     const f32x4 h1v = ld4(d.PH1T + (size_t)(n0 + c) * B + row0 + 4 * g);
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
+    const float alpha = alpha_step(d.ctl, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     lds_barrier();
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
 #pragma unroll
@@ -850,8 +846,8 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d) {
 // The extra last block computes the step's diagnostics.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float g, float step_size, float bc2s) {
-    m = m + (1.0f - ADAM_B1) * (g - m);
-    v = v * ADAM_B2 + (1.0f - ADAM_B2) * g * g;
+    m = m + ADAM_1MB1 * (g - m);
+    v = v * ADAM_B2 + ADAM_1MB2 * g * g;
     const float denom = sqrtf(v) / bc2s + ADAM_EPS;
     p = p + (-step_size * m) / denom;
 }
@@ -915,7 +911,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             m4 = ld4(J.MT + ot);
             v4 = ld4(J.VT + ot);
         }
-        const double bc1 = sload(&cp->bc1), bc2sd = sload(&cp->bc2s);
+        const double bc1 = sa.bc1, bc2sd = sa.bc2s;
         const bool polyak = (J.TP != nullptr) && (sa.step_now % d.period == 0);
         f32x4 tp4 = {0.f, 0.f, 0.f, 0.f};
         if (polyak && own_valid) {
@@ -992,7 +988,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         }
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
-        const float alpha = sload(&cp->alpha), alpha_loss = sload(&cp->alpha_loss);
+        const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
+        const float alpha = as.alpha, alpha_loss = as.alpha_loss;
         const int loop_pos = sa.loop_pos;
         double sm[NSTAT], sq[NSTAT], ls4[4];
         float mx[NSTAT], mn[NSTAT];
@@ -1060,7 +1057,12 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
                 double s = 0;
                 for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24 + q];
                 v = (float)(s / B);
-            } else if (q == 4) { v = alpha; di = SAC_D_ALPHA; }
+            } else if (q == 4) {
+                v = alpha; di = SAC_D_ALPHA;
+                Ctl *cw = d.ctl;                   // the step's only writer of the entropy-coefficient state
+                cw->log_alpha = as.log_alpha; cw->a_m = as.m; cw->a_v = as.v; cw->alpha = as.alpha;
+                cw->alpha_loss = as.alpha_loss;
+            }
             else if (q == 5) { v = alpha_loss; di = SAC_D_ALPHA_LOSS; }
             else { di = 30 + (q - 6); }
             d.diag_last[di] = v;
@@ -1197,16 +1199,17 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
     const int NB = t->NB;
-    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0};
+    const double tt = (double)(t->adam_t + 1);
+    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
     hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPLIT * NB), dim3(256), t->lds_fa, s, d, S, SL);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPLIT * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * SPLIT * NB), dim3(256), t->lds_qb, s, d, S, SL);
+    hipLaunchKernelGGL(k_q_bwd, dim3(4 * SPLIT * NB), dim3(256), t->lds_qb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[3], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d);
-    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d);
+    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d, sa);
+    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
     if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
