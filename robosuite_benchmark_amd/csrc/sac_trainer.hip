@@ -434,10 +434,15 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     float *X1 = X0 + RB * KLmax;         // [16][256]  full first hidden layer
     float *XS = X1 + RB * H;             // [16][64]   this block's 64 columns of the second one
     float *red = XS + RB * 64;           // split-K scratch 4*NTH*256
-    const int npi = 2 * SPLIT * NB;
-    const bool is_pi = (int)blockIdx.x < npi;
-    const int b = is_pi ? blockIdx.x : blockIdx.x - npi;
-    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, sq = (b >> 2) / NB;   // sq: side (pi) / twin (Q)
+    // XCD-aware block -> work map (speed only): workgroups are dealt round-robin over the 8 XCDs, and each
+    // XCD's L2 has to pull every weight matrix its workgroups touch from the Infinity Cache once per launch
+    // (weights change every step).  Blocks with b % 8 in {0..3} take the policy, {4,5} Q1, {6,7} Q2, so an
+    // XCD fetches ONE network instead of all three.
+    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
+    const bool is_pi = xr < 4;
+    const int b = is_pi ? 4 * xq + xr : 2 * xq + (xr & 1);          // index inside the network's 8*NB / 4*NB blocks
+    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB;
+    const int sq = is_pi ? (b >> 2) / NB : ((xr - 4) >> 1);          // sq: side (pi) / twin (Q)
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const int row = threadIdx.x >> 4, p16 = threadIdx.x & 15;
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     const int n0 = 64 * part + 16 * wave;                    // this wave's tile of the split layer
     const float *obs = S + ((is_pi && sq) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
 
+    STAMP(0, 0);
     // ---- requests, in consumption order ----
     RowRegs<WIDE ? 32 : 8> rows;
     rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, is_pi ? 0 : A, A);
@@ -473,6 +479,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     SB();
     rows.commit(X0, KL0, K0);
     lds_barrier();
+    STAMP(0, 1);
     {   // first layer, all 256 features (recomputed by the four blocks of this row-block)
         f32x4 acc[4] = {};
         if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
@@ -481,6 +488,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
     }
     lds_barrier();
+    STAMP(0, 2);
     {   // this block's 64 columns of the 256x256 layer
         f32x4 acc[1] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
@@ -488,6 +496,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         slice_epilogue(acc[0], bv1, wave, XS, h2T ? h2T + (size_t)(n0 + c) * B : nullptr, row0);
     }
     lds_barrier();
+    STAMP(0, 3);
     if (is_pi) {
         // partial head pre-activations over these 64 columns (each wave contracts its own 16)
         f32x4 acc[NTH] = {};
@@ -501,6 +510,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         s = group16_sum(s);
         if (p16 == 0) d.qpart[((size_t)sq * SPLIT + part) * B + row0 + row] = s;
     }
+    STAMP(0, 4);
 }
 
 template <int NTH, bool WIDE>
@@ -512,8 +522,11 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     float *X1 = XQ + RB * KLQ;           // [16][256]
     float *XS = X1 + RB * H;             // [16][64]
     float *red = XS + RB * 64;           // 64 floats
-    const int b = blockIdx.x;
-    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, p4 = (b >> 2) / NB;   // p4: Q1, Q2 (s,a_new); T1, T2 (s',a')
+    // XCD-aware map (see k_fwd_a): b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> T1, {6,7} -> T2
+    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
+    const int p4 = xr >> 1;                                          // Q1, Q2 on (s,a_new); T1, T2 on (s',a')
+    const int b = 2 * xq + (xr & 1);                                 // index inside the network's 4*NB blocks
+    const int part = b & (SPLIT - 1), rb = b >> 2;
     const int side = p4 >> 1, pass = 2 + p4;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
@@ -522,6 +535,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     const int n0 = 64 * part + 16 * wave;
     const bool own_s = (p4 == 0) && (part == 0), own_n = (p4 == 2) && (part == 0);
 
+    STAMP(1, 0);
     // ---- requests, in consumption order ----
     float hm[SPLIT], hr[SPLIT], hbm = 0.f, hbr = 0.f, epsin = 0.f;
     const float *epp = side ? d.eps2 : d.eps1;
@@ -555,6 +569,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
     USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
     rows.commit(XQ, KLQ, d.KQ, O, O + A);
+    STAMP(1, 1);
     // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
     float lp = 0.f;
     if (a < A) {
@@ -596,6 +611,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         for (int i = 0; i < RB; ++i) s += red[i];
         d.part_logpi[rb] = s;
     }
+    STAMP(1, 2);
     // ---- Q / target-Q net on cat(obs, action) ----
     {
         f32x4 acc[4] = {};
@@ -605,6 +621,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
     }
     lds_barrier();
+    STAMP(1, 3);
     {
         f32x4 acc[1] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
@@ -617,6 +634,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, 64)] * w3[u];
     s = group16_sum(s);
     if (a == 0) d.qpart[((size_t)pass * SPLIT + part) * B + grow] = s;
+    STAMP(1, 4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -630,12 +648,15 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     float *XS = X2 + RB * H;         // dL/dh1, this block's 64 features [16][64] (actor)
     float *red = XS + RB * 64;       // 1024 floats
     __shared__ float s_dq[RB];
-    const int b = blockIdx.x;
-    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB, pass = (b >> 2) / NB;
+    // XCD-aware map (see k_fwd_a): b % 8 in {0..3} -> twin Q1, {4..7} -> twin Q2
+    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
+    const int qi = xr >> 2;                // which twin
+    const int b = 4 * xq + (xr & 3);       // index inside the twin's 8*NB blocks: critic first, then actor
+    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB;
+    const bool critic = ((b >> 2) / NB) == 0;
+    const int pass = (critic ? 0 : 2) + qi;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const bool critic = pass < 2;
-    const int qi = pass & 1;               // which twin
     const float *P = d.P[1 + qi];
     const float *PT = d.PT[1 + qi];
     const float invB = 1.0f / (float)B;
@@ -863,6 +884,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     const Ctl *cp = d.ctl;
 
     if ((int)blockIdx.x < T.njobs) {
+        STAMP(4, 0);
         int li = 0;
 #pragma unroll
         for (int q = 1; q < NDW; ++q) li = ((int)blockIdx.x >= T.job0[q]) ? q : li;
@@ -956,6 +978,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         bsum += __shfl_xor(bsum, 32);
         if (g == 0) redb[wave * 16 + r] = bsum;
         lds_barrier();
+        STAMP(4, 1);
         const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
         if (own_valid) {
             f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
@@ -986,6 +1009,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (J.gb) J.gb[n] = gb;
             if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
+        STAMP(4, 2);
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
         const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);

@@ -10,10 +10,12 @@ out = np.zeros(5*512*16, np.uint64)
 lib.sac_fetch_stamps.argtypes = [C.c_void_p, C.c_void_p]
 lib.sac_fetch_stamps(tr._h, out.ctypes.data_as(C.c_void_p))
 st = out.reshape(5, 512, 16).astype(np.int64)
-order = [0,1,8,9,2,3,10,11,12,13,14,4,5,6,7]
-names = ["start","prologue+sync","piG0","epi0","issueQ1+sync","piG1","epi1","issueQ2+sync","headG","reduce","commit+elem","tail(ticket)+sync","QG0+epi+sync","QG1","end"]
-w = st[0,:96]
-for p_ in range(2,6):
-    ww = w[16*p_:16*p_+16]
-    t = [np.median(ww[:,i]) for i in order]
-    print("pass", p_, " ".join(f"{names[k+1]}={(t[k+1]-t[k])/100.0:.2f}" for k in range(len(order)-1)), " total", (t[-1]-t[0])/100.0)
+for kid, nb, name in ((0,256,"k_fwd_a"),(1,256,"k_fwd_b"),(4,245,"k_dw_adam")):
+    w = st[kid,:nb]
+    n = max(i for i in range(16) if w[:,i].max() > 0) + 1
+    t0 = w[:,0].min()
+    segs = [np.median(w[:,i]-w[:,i-1])/100.0 for i in range(1,n)]
+    print(name, "start spread", (w[:,0].max()-t0)/100.0, "segs", [round(float(x),2) for x in segs], "block median", np.median(w[:,n-1]-w[:,0])/100.0, "first->last", (w[:,n-1].max()-t0)/100.0)
+    if kid == 0:
+        for lo,hi,nm in ((0,128,"pi"),(128,256,"critic")):
+            ww=w[lo:hi]; print("   ", nm, [round(float(np.median(ww[:,i]-ww[:,i-1])/100.0),2) for i in range(1,n)])
