@@ -407,49 +407,55 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 //   D k_pi_bwd   4*B/16 WGs  head gradient (reparameterised, analytic), dL/dh
 //   E k_dw_adam              (below)
 // ------------------------------------------------------------------------------------------
-constexpr int SPLIT = 4;
-constexpr int RDS = 8;            // ring depth of a 64-column slice (one tile per wave): 8 k-chunks = 8 KB per wave in
-                                  // flight; measured 4: -1 %, 8: best, 16 (whole sweep up front): -7 %
+// SP = column split of the 256-wide layers (4, 2 or 1 workgroups per row-block), NTW = 4 / SP tiles per wave.
+// Small batches want SP = 4 (more CUs, 64 KB of weights each); B >= 512 already fills the chip with
+// row-blocks, so it takes SP = 2 / 1 (fewer, fatter workgroups; less recomputation of the first layers).
+constexpr int ring_depth(int ntw) { return ntw == 1 ? 8 : 4; }   // k-chunks in flight: 8 KB (1 tile) .. 16 KB (4 tiles) per wave
 
-// relu(acc + bias) of this wave's single tile -> local slice buffer XS[16][64] and (optionally) the
-// feature-major global row of that feature
-__device__ __forceinline__ void slice_epilogue(const f32x4 &acc, float bv, int wave, float *XS, float *outT_row,
-                                               int row0) {
+// relu(acc + bias) of this wave's NTW tiles -> local slice buffer XS[16][64*NTW] and (optionally) the
+// feature-major global rows of those features
+template <int NTW>
+__device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const float (&bv)[NTW], int wave, float *XS,
+                                               float *outT /* row of feature n_first */, int B, int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[i] = fmaxf(acc[i] + bv, 0.f);
-        XS[lds_off(4 * g + i, 16 * wave + c, 64)] = v[i];
+    for (int t = 0; t < NTW; ++t) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = fmaxf(acc[t][i] + bv[t], 0.f);
+            XS[lds_off(4 * g + i, 16 * (NTW * wave + t) + c, 64 * NTW)] = v[i];
+        }
+        if (outT) st4(outT + (size_t)(16 * t + c) * B + row0 + 4 * g, v);
     }
-    if (outT_row) st4(outT_row + row0 + 4 * g, v);
 }
 
-template <int NTH, bool WIDE>
+template <int NTH, bool WIDE, int SP>
 __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ S, SlotLayout SL) {
+    constexpr int NTW = 4 / SP, SW = 64 * NTW;               // tiles per wave, slice width
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
     const int KLmax = (d.KQ + 63) & ~63;
     float *X0 = lds;                     // [16][KL0]
     float *X1 = X0 + RB * KLmax;         // [16][256]  full first hidden layer
-    float *XS = X1 + RB * H;             // [16][64]   this block's 64 columns of the second one
-    float *red = XS + RB * 64;           // split-K scratch 4*NTH*256
+    float *XS = X1 + RB * H;             // [16][SW]   this block's columns of the second one
+    float *red = XS + RB * SW;           // split-K scratch 4*NTH*256
     // XCD-aware block -> work map (speed only): workgroups are dealt round-robin over the 8 XCDs, and each
     // XCD's L2 has to pull every weight matrix its workgroups touch from the Infinity Cache once per launch
     // (weights change every step).  Blocks with b % 8 in {0..3} take the policy, {4,5} Q1, {6,7} Q2, so an
     // XCD fetches ONE network instead of all three.
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
     const bool is_pi = xr < 4;
-    const int b = is_pi ? 4 * xq + xr : 2 * xq + (xr & 1);          // index inside the network's 8*NB / 4*NB blocks
-    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB;
-    const int sq = is_pi ? (b >> 2) / NB : ((xr - 4) >> 1);          // sq: side (pi) / twin (Q)
+    const int b = is_pi ? 4 * xq + xr : 2 * xq + (xr & 1);          // index inside the network's blocks
+    const int part = b % SP, rb = (b / SP) % NB;
+    const int sq = is_pi ? (b / SP) / NB : ((xr - 4) >> 1);          // sq: side (pi) / twin (Q)
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const int row = threadIdx.x >> 4, p16 = threadIdx.x & 15;
     const float *P = is_pi ? d.P[0] : d.P[1 + sq];
     const Layer L0 = is_pi ? d.LP[0] : d.LQ[0], L1 = is_pi ? d.LP[1] : d.LQ[1], L2 = is_pi ? d.LP[2] : d.LQ[2];
     const int K0 = is_pi ? d.KP : d.KQ, KL0 = (K0 + 63) & ~63;
-    const int n0 = 64 * part + 16 * wave;                    // this wave's tile of the split layer
+    const int n0 = SW * part + 16 * NTW * wave;              // this wave's first tile of the split layer
     const float *obs = S + ((is_pi && sq) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
 
     STAMP(0, 0);
@@ -463,87 +469,92 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
     SB();
-    WRing<1, RDS> r1;
+    WRing<NTW, ring_depth(NTW)> r1;
     r1.init(P + L1.offW, H, n0, 16);
     r1.fill(H >> 4);
-    const float bv1 = P[L1.offB + n0 + c];
-    WRing<NTH, 1> rh;                                        // pi: head rows x this wave's 16 columns
-    float w3[4] = {0.f, 0.f, 0.f, 0.f};
+    float bv1[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bv1[t] = P[L1.offB + n0 + 16 * t + c];
+    WRing<NTH, NTW> rh;                                      // pi: head rows x this wave's 16*NTW columns
+    float w3[4 * NTW];
+#pragma unroll
+    for (int u = 0; u < 4 * NTW; ++u) w3[u] = 0.f;
     if (is_pi) {
-        rh.init(P + L2.offW, H, 0, 16, 4 * part + wave);
-        rh.fill(1);
+        rh.init(P + L2.offW, H, 0, 16, 4 * NTW * part + NTW * wave);
+        rh.fill(NTW);
     } else {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w3[u] = P[L2.offW + 64 * part + p16 + 16 * u];
+        for (int u = 0; u < 4 * NTW; ++u) w3[u] = P[L2.offW + SW * part + p16 + 16 * u];
     }
     SB();
     rows.commit(X0, KL0, K0);
     lds_barrier();
     STAMP(0, 1);
-    {   // first layer, all 256 features (recomputed by the four blocks of this row-block)
+    {   // first layer, all 256 features (recomputed by the SP blocks of this row-block)
         f32x4 acc[4] = {};
         if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
         else gemm_straight(r0, X0, KL0, K0 >> 4, acc);
         float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
     }
     lds_barrier();
     STAMP(0, 2);
-    {   // this block's 64 columns of the 256x256 layer
-        f32x4 acc[1] = {};
+    {   // this block's columns of the 256x256 layer
+        f32x4 acc[NTW] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
         float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
-        slice_epilogue(acc[0], bv1, wave, XS, h2T ? h2T + (size_t)(n0 + c) * B : nullptr, row0);
+        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
     lds_barrier();
     STAMP(0, 3);
     if (is_pi) {
-        // partial head pre-activations over these 64 columns (each wave contracts its own 16)
+        // partial head pre-activations over these columns (each wave contracts its own 16*NTW)
         f32x4 acc[NTH] = {};
-        gemm_ring(rh, XS, 64, 1, acc, wave);
-        splitk_reduce<NTH>(acc, nullptr, red, d.headpart + ((size_t)(sq * NB + rb) * SPLIT + part) * (RB * 32), 32);
+        gemm_ring(rh, XS, SW, NTW, acc, NTW * wave);
+        splitk_reduce<NTH>(acc, nullptr, red, d.headpart + ((size_t)(sq * NB + rb) * SP + part) * (RB * 32), 32);
     } else {
-        // partial q over these 64 columns
+        // partial q over these columns
         float s = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += XS[lds_off(row, p16 + 16 * u, 64)] * w3[u];
+        for (int u = 0; u < 4 * NTW; ++u) s += XS[lds_off(row, p16 + 16 * u, SW)] * w3[u];
         s = group16_sum(s);
-        if (p16 == 0) d.qpart[((size_t)sq * SPLIT + part) * B + row0 + row] = s;
+        if (p16 == 0) d.qpart[((size_t)sq * SP + part) * B + row0 + row] = s;
     }
     STAMP(0, 4);
 }
 
-template <int NTH, bool WIDE>
+template <int NTH, bool WIDE, int SP>
 __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
     const int KLQ = (d.KQ + 63) & ~63;
     float *XQ = lds;                     // [16][KLQ]  cat(obs, action)
     float *X1 = XQ + RB * KLQ;           // [16][256]
-    float *XS = X1 + RB * H;             // [16][64]
-    float *red = XS + RB * 64;           // 64 floats
+    float *XS = X1 + RB * H;             // [16][SW]
+    float *red = XS + RB * SW;           // 64 floats
     // XCD-aware map (see k_fwd_a): b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> T1, {6,7} -> T2
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
     const int p4 = xr >> 1;                                          // Q1, Q2 on (s,a_new); T1, T2 on (s',a')
-    const int b = 2 * xq + (xr & 1);                                 // index inside the network's 4*NB blocks
-    const int part = b & (SPLIT - 1), rb = b >> 2;
+    const int b = 2 * xq + (xr & 1);                                 // index inside the network's SP*NB blocks
+    const int part = b % SP, rb = b / SP;
     const int side = p4 >> 1, pass = 2 + p4;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15, grow = row0 + row;
-    const float *PQ = d.P[(p4 < 2) ? 1 + p4 : 1 + p4];       // nets 1,2 (Q1,Q2) and 3,4 (T1,T2)
-    const int n0 = 64 * part + 16 * wave;
+    const float *PQ = d.P[1 + p4];                           // nets 1,2 (Q1,Q2) and 3,4 (T1,T2)
+    const int n0 = SW * part + 16 * NTW * wave;
     const bool own_s = (p4 == 0) && (part == 0), own_n = (p4 == 2) && (part == 0);
 
     STAMP(1, 0);
     // ---- requests, in consumption order ----
-    float hm[SPLIT], hr[SPLIT], hbm = 0.f, hbr = 0.f, epsin = 0.f;
+    float hm[SP], hr[SP], hbm = 0.f, hbr = 0.f, epsin = 0.f;
     const float *epp = side ? d.eps2 : d.eps1;
     {
-        const float *hp = d.headpart + (size_t)(side * NB + rb) * SPLIT * (RB * 32) + row * 32;
+        const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
         const int am = (a < A) ? a : 0;
 #pragma unroll
-        for (int p = 0; p < SPLIT; ++p) { hm[p] = hp[p * (RB * 32) + am]; hr[p] = hp[p * (RB * 32) + A + am]; }
+        for (int p = 0; p < SP; ++p) { hm[p] = hp[p * (RB * 32) + am]; hr[p] = hp[p * (RB * 32) + A + am]; }
         hbm = d.P[0][d.LP[2].offB + am];
         hbr = d.P[0][d.LP[2].offB + A + am];
         if (epp) epsin = epp[grow * A + am];
@@ -557,24 +568,28 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
     SB();
-    WRing<1, RDS> r1;
+    WRing<NTW, ring_depth(NTW)> r1;
     r1.init(PQ + d.LQ[1].offW, H, n0, 16);
     r1.fill(H >> 4);
-    const float bv1 = PQ[d.LQ[1].offB + n0 + c];
-    float w3[4];
+    float bv1[NTW];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) w3[u] = PQ[d.LQ[2].offW + 64 * part + a + 16 * u];
+    for (int t = 0; t < NTW; ++t) bv1[t] = PQ[d.LQ[1].offB + n0 + 16 * t + c];
+    float w3[4 * NTW];
+#pragma unroll
+    for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
     SB();
 #pragma unroll
-    for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
+    for (int p = 0; p < SP; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
     USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
     rows.commit(XQ, KLQ, d.KQ, O, O + A);
     STAMP(1, 1);
     // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
     float lp = 0.f;
     if (a < A) {
-        const float mean = (((hm[0] + hm[1]) + hm[2]) + hm[3]) + hbm;
-        const float raw = (((hr[0] + hr[1]) + hr[2]) + hr[3]) + hbr;
+        float mean = hm[0], raw = hr[0];
+#pragma unroll
+        for (int p = 1; p < SP; ++p) { mean += hm[p]; raw += hr[p]; }     // fixed order
+        mean += hbm; raw += hbr;
         const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
         const float stdv = expf(lstd);
         const float eps = epp ? epsin
@@ -618,42 +633,44 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, d.KQ >> 4, acc);
         else gemm_straight(r0, XQ, KLQ, d.KQ >> 4, acc);
         float *h1T = (p4 < 2) ? d.QH1T + (size_t)pass * H * B : nullptr;
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave == part) ? h1T : nullptr, B, row0);
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
     }
     lds_barrier();
     STAMP(1, 3);
     {
-        f32x4 acc[1] = {};
+        f32x4 acc[NTW] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
-        slice_epilogue(acc[0], bv1, wave, XS, h2T ? h2T + (size_t)(n0 + c) * B : nullptr, row0);
+        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
     lds_barrier();
     float s = 0.f;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, 64)] * w3[u];
+    for (int u = 0; u < 4 * NTW; ++u) s += XS[lds_off(row, a + 16 * u, SW)] * w3[u];
     s = group16_sum(s);
-    if (a == 0) d.qpart[((size_t)pass * SPLIT + part) * B + grow] = s;
+    if (a == 0) d.qpart[((size_t)pass * SP + part) * B + grow] = s;
     STAMP(1, 4);
 }
 
 // ------------------------------------------------------------------------------------------
-// C: Q backward.  pass 0/1: critic Q1/Q2 (dL/dh kept for dW); pass 2/3: actor path through Q1/Q2
-// down to d/da_new (input gradient only; partial over this block's 64 first-layer features).
+// C: Q backward.  critic Q1/Q2 (dL/dh kept for dW) and the actor path through Q1/Q2 down to
+// d/da_new (input gradient only; partial over this block's first-layer features).
 // ------------------------------------------------------------------------------------------
+template <int SP>
 __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, NB = d.NB;
-    float *X2 = lds;                 // dL/dh2 row-block [16][256] (recomputed by the four blocks)
-    float *XS = X2 + RB * H;         // dL/dh1, this block's 64 features [16][64] (actor)
-    float *red = XS + RB * 64;       // 1024 floats
+    float *X2 = lds;                 // dL/dh2 row-block [16][256] (recomputed by the SP blocks)
+    float *XS = X2 + RB * H;         // dL/dh1, this block's features [16][SW] (actor)
+    float *red = XS + RB * SW;       // 1024 floats
     __shared__ float s_dq[RB];
     // XCD-aware map (see k_fwd_a): b % 8 in {0..3} -> twin Q1, {4..7} -> twin Q2
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
     const int qi = xr >> 2;                // which twin
-    const int b = 4 * xq + (xr & 3);       // index inside the twin's 8*NB blocks: critic first, then actor
-    const int part = b & (SPLIT - 1), rb = (b >> 2) % NB;
-    const bool critic = ((b >> 2) / NB) == 0;
+    const int b = 4 * xq + (xr & 3);       // index inside the twin's 2*SP*NB blocks: critic first, then actor
+    const int part = b % SP, rb = (b / SP) % NB;
+    const bool critic = ((b / SP) / NB) == 0;
     const int pass = (critic ? 0 : 2) + qi;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -662,22 +679,22 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     const float invB = 1.0f / (float)B;
     const float *h2T = d.QH2T + (size_t)pass * H * B;
     const float *h1T = d.QH1T + (size_t)pass * H * B;
-    const int n0 = 64 * part + 16 * wave;
+    const int n0 = SW * part + 16 * NTW * wave;
     const long long oB3 = d.LQ[2].offB;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const float b3a = sload(d.P[critic ? 3 : 1] + oB3), b3b = sload(d.P[critic ? 4 : 2] + oB3), b3q = sload(P + oB3);
-    float qa[SPLIT], qb[SPLIT], qq[SPLIT], in_c = 0.f, in_r = 0.f, in_t = 0.f;      // loads only: no use before SB
+    float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;      // loads only: no use before SB
 #pragma unroll
-    for (int p = 0; p < SPLIT; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
+    for (int p = 0; p < SP; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
         const int pa = critic ? 4 : 2, pb = critic ? 5 : 3;
 #pragma unroll
-        for (int p = 0; p < SPLIT; ++p) {
-            qa[p] = d.qpart[((size_t)pa * SPLIT + p) * B + r];
-            qb[p] = d.qpart[((size_t)pb * SPLIT + p) * B + r];
-            if (critic) qq[p] = d.qpart[((size_t)qi * SPLIT + p) * B + r];
+        for (int p = 0; p < SP; ++p) {
+            qa[p] = d.qpart[((size_t)pa * SP + p) * B + r];
+            qb[p] = d.qpart[((size_t)pb * SP + p) * B + r];
+            if (critic) qq[p] = d.qpart[((size_t)qi * SP + p) * B + r];
         }
         if (critic) { in_c = d.logpi2[r]; in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r]; }
     }
@@ -687,29 +704,34 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
     SB();
-    WRing<1, RDS> r1;
+    WRing<NTW, ring_depth(NTW)> r1;
     r1.init(PT + d.LQ[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
-    const f32x4 h1v = ld4(h1T + (size_t)(n0 + c) * B + row0 + 4 * g);
-    WRing<1, 1> ra;
+    f32x4 h1v[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(h1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
+    WRing<1, NTW> ra;
     if (!critic) {
-        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * part + wave);
-        ra.fill(1);
+        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * NTW * part + NTW * wave);
+        ra.fill(NTW);
     }
     SB();
     // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
     const float alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
 #pragma unroll
-    for (int p = 0; p < SPLIT; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
+    for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
-        const float va = (((qa[0] + qa[1]) + qa[2]) + qa[3]) + b3a;      // T1 (critic) / Q1(s,a_new) (actor)
-        const float vb = (((qb[0] + qb[1]) + qb[2]) + qb[3]) + b3b;      // T2          / Q2(s,a_new)
+        float va = qa[0], vb = qb[0], vq = qq[0];
+#pragma unroll
+        for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; vq += qq[p]; }      // fixed order
+        va += b3a;                                                       // T1 (critic) / Q1(s,a_new) (actor)
+        vb += b3b;                                                       // T2          / Q2(s,a_new)
         float dq;
         if (critic) {
-            const float vq = (((qq[0] + qq[1]) + qq[2]) + qq[3]) + b3q;  // Q_i(s,a)
+            vq += b3q;                                                   // Q_i(s,a)
             const float tq = fminf(va, vb) - alpha * in_c;
             const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
             dq = 2.0f * (vq - yv) * invB;
@@ -727,9 +749,9 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         s_dq[threadIdx.x] = dq;
     }
     lds_barrier();
-    // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner quarter
+    // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner block
     {
-        float *outT = (critic && (k >> 6) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
+        float *outT = (critic && (k / SW) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             f32x4 gv;
@@ -742,25 +764,28 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         }
     }
     lds_barrier();
-    // dL/dh1[:, 64 features] = (dL/dh2 . W2)[:, slice] * relu'(h1)
+    // dL/dh1[:, this block's features] = (dL/dh2 . W2)[:, slice] * relu'(h1)
     {
-        f32x4 acc[1] = {};
+        f32x4 acc[NTW] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
-        f32x4 gv;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gv[i] = (h1v[i] > 0.f) ? acc[0][i] : 0.f;
-            if (!critic) XS[lds_off(4 * g + i, 16 * wave + c, 64)] = gv[i];
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 gv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
+                if (!critic) XS[lds_off(4 * g + i, 16 * (NTW * wave + t) + c, SW)] = gv[i];
+            }
+            if (critic) st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
         }
-        if (critic) st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + c) * B + row0 + 4 * g, gv);
     }
     if (critic) return;
     lds_barrier();
     // partial d/da_new = dL/dh1[:, slice] . W1[slice, O:O+A]   -> dapart[qi][part][row][16]
     {
         f32x4 acc[1] = {};
-        gemm_ring(ra, XS, 64, 1, acc, wave);
-        splitk_reduce<1>(acc, nullptr, red, d.dapart + (((size_t)qi * SPLIT + part) * B + row0) * 16, 16);
+        gemm_ring(ra, XS, SW, NTW, acc, NTW * wave);
+        splitk_reduce<1>(acc, nullptr, red, d.dapart + (((size_t)qi * SP + part) * B + row0) * 16, 16);
     }
 }
 
@@ -770,29 +795,30 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
 //   dL/dmu     = dL/dz                      (the Normal terms cancel exactly under rsample)
 //   dL/dlogstd = dL/dz * std*eps - alpha/B  (masked by the clamp)
 // ------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, int SP>
 __global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
+    constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, A = d.A;
     float *XH = lds;                 // [16][64] head gradient row-block
-    float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the four blocks)
-    const int part = blockIdx.x & (SPLIT - 1), rb = blockIdx.x >> 2, row0 = rb * RB;
+    float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the SP blocks)
+    const int part = blockIdx.x % SP, rb = blockIdx.x / SP, row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const float *PT = d.PT[0];
     const float invB = 1.0f / (float)B;
-    const int n0 = 64 * part + 16 * wave;
+    const int n0 = SW * part + 16 * NTW * wave;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int gi = (row0 + row) * 16 + a;
-    float act = 0.f, dap[2 * SPLIT], lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
+    float act = 0.f, dap[2 * SP], lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
 #pragma unroll
-    for (int p = 0; p < 2 * SPLIT; ++p) dap[p] = 0.f;
+    for (int p = 0; p < 2 * SP; ++p) dap[p] = 0.f;
     if (a < A) {
         act = d.anew[gi];
 #pragma unroll
-        for (int p = 0; p < 2 * SPLIT; ++p) dap[p] = d.dapart[(size_t)p * B * 16 + gi];
+        for (int p = 0; p < 2 * SP; ++p) dap[p] = d.dapart[(size_t)p * B * 16 + gi];
         lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
     }
     SB();
@@ -803,20 +829,24 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
     SB();
-    WRing<1, RDS> r1;
+    WRing<NTW, ring_depth(NTW)> r1;
     r1.init(PT + d.LP[1].offWt, H, n0, 16);
     r1.fill(H >> 4);
     SB();
-    const f32x4 h1v = ld4(d.PH1T + (size_t)(n0 + c) * B + row0 + 4 * g);
+    f32x4 h1v[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(d.PH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
     const float alpha = alpha_step(d.ctl, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     lds_barrier();
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
 #pragma unroll
-    for (int p = 0; p < 2 * SPLIT; ++p) USE_FROM_HERE(dap[p]);
+    for (int p = 0; p < 2 * SP; ++p) USE_FROM_HERE(dap[p]);
     if (a < A) {
-        const float da1 = ((dap[0] + dap[1]) + dap[2]) + dap[3], da2 = ((dap[4] + dap[5]) + dap[6]) + dap[7];
+        float da1 = dap[0], da2 = dap[SP];
+#pragma unroll
+        for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }          // fixed order
         const float om = 1.0f - act * act;
         const float dz = (da1 + da2) * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
         const float stdv = expf(lsv);
@@ -841,17 +871,20 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
                 gv[i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
                 X2[lds_off(4 * g + i, n, H)] = gv[i];
             }
-            if (wave == part) st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
+            if (wave / NTW == part) st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
     lds_barrier();
     {
-        f32x4 acc[1] = {};
+        f32x4 acc[NTW] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
-        f32x4 gv;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gv[i] = (h1v[i] > 0.f) ? acc[0][i] : 0.f;
-        st4(d.dPH1T + (size_t)(n0 + c) * B + row0 + 4 * g, gv);
+        for (int t = 0; t < NTW; ++t) {
+            f32x4 gv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
+            st4(d.dPH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
+        }
     }
 }
 
@@ -1107,7 +1140,7 @@ struct sac_trainer {
     sac_config_t cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    int B = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0;
+    int B = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0, SP = 4;
     Net net[5];
     Dev dev{};
     DwTable dw{};
@@ -1127,6 +1160,8 @@ struct sac_trainer {
     size_t lds_qb = 0, lds_pb = 0;
     void (*fwd_a)(Dev, const float *, SlotLayout) = nullptr;
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    void (*q_bwd)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    void (*pi_bwd)(Dev, StepArg) = nullptr;
     size_t lds_fa = 0, lds_fb = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
 };
@@ -1225,15 +1260,15 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     const int NB = t->NB;
     const double tt = (double)(t->adam_t + 1);
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
+    const int SPv = t->SP;
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPLIT * NB), dim3(256), t->lds_fa, s, d, S, SL);
+    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPLIT * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
+    hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(k_q_bwd, dim3(4 * SPLIT * NB), dim3(256), t->lds_qb, s, d, S, SL, sa);
+    hipLaunchKernelGGL(t->q_bwd, dim3(4 * SPv * NB), dim3(256), t->lds_qb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[3], s));
-    if (t->NH == 16) hipLaunchKernelGGL(k_policy_bwd<1>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d, sa);
-    else hipLaunchKernelGGL(k_policy_bwd<2>, dim3(SPLIT * NB), dim3(256), t->lds_pb, s, d, sa);
+    hipLaunchKernelGGL(t->pi_bwd, dim3(SPv * NB), dim3(256), t->lds_pb, s, d, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
     if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
@@ -1275,6 +1310,9 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     t->B = cfg->batch; t->O = cfg->obs_dim; t->A = cfg->act_dim;
     t->KP = round_up(t->O, 16); t->KQ = round_up(t->O + t->A, 16); t->NH = round_up(2 * t->A, 16);
     t->NB = t->B / 16;
+    // column split: small batches spread every 256-wide layer over 4 workgroups per row-block; once the
+    // row-blocks alone fill the 256 CUs (B >= 512) fewer, fatter workgroups win.  SP*NB stays even (XCD map).
+    t->SP = (t->NB <= 16) ? 4 : (t->NB <= 32 ? 2 : ((t->NB & 1) ? 2 : 1));
     SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1303,7 +1341,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
         {&d.epsv, 16LL * B}, {&d.logpi, B}, {&d.a2, 16LL * B}, {&d.logpi2, B}, {&d.part_logpi, round_up(t->NB, 64)},
         {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B},
         {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
-        {&d.headpart, 2LL * t->NB * SPLIT * RB * 32}, {&d.qpart, 6LL * SPLIT * B}, {&d.dapart, 2LL * SPLIT * B * 16},
+        {&d.headpart, 2LL * t->NB * 4 * RB * 32}, {&d.qpart, 6LL * 4 * B}, {&d.dapart, 2LL * 4 * B * 16},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
     long long tot = 0;
     for (auto &p : parts) tot += round_up64(p.second, 64);
@@ -1371,16 +1409,26 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
     (void)KL0p;
-    t->lds_fa = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + 4 * nth * 256);
-    t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + 64);
-    t->lds_qb = sizeof(float) * (size_t)(RB * H + RB * 64 + 1024);
+    const int sw = 64 * (4 / t->SP);
+    t->lds_fa = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 4 * nth * 256);
+    t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 64);
+    t->lds_qb = sizeof(float) * (size_t)(RB * H + RB * sw + 1024);
     t->lds_pb = sizeof(float) * (size_t)(RB * 64 + RB * H);
     SAC_REQUIRE(t->lds_fa <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     const bool wide = t->KQ > 16 * RD0;
-    t->fwd_a = (nth == 1) ? (wide ? &k_fwd_a<1, true> : &k_fwd_a<1, false>)
-                          : (wide ? &k_fwd_a<2, true> : &k_fwd_a<2, false>);
-    t->fwd_b = (nth == 1) ? (wide ? &k_fwd_b<1, true> : &k_fwd_b<1, false>)
-                          : (wide ? &k_fwd_b<2, true> : &k_fwd_b<2, false>);
+#define SAC_PICK(SPV)                                                                                      \
+    do {                                                                                                   \
+        t->fwd_a = (nth == 1) ? (wide ? &k_fwd_a<1, true, SPV> : &k_fwd_a<1, false, SPV>)                   \
+                              : (wide ? &k_fwd_a<2, true, SPV> : &k_fwd_a<2, false, SPV>);                  \
+        t->fwd_b = (nth == 1) ? (wide ? &k_fwd_b<1, true, SPV> : &k_fwd_b<1, false, SPV>)                   \
+                              : (wide ? &k_fwd_b<2, true, SPV> : &k_fwd_b<2, false, SPV>);                  \
+        t->q_bwd = &k_q_bwd<SPV>;                                                                          \
+        t->pi_bwd = (nth == 1) ? &k_policy_bwd<1, SPV> : &k_policy_bwd<2, SPV>;                            \
+    } while (0)
+    if (t->SP == 4) SAC_PICK(4);
+    else if (t->SP == 2) SAC_PICK(2);
+    else SAC_PICK(1);
+#undef SAC_PICK
     if (t->lds_fa > 64 * 1024) {
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fa));
