@@ -22,4 +22,16 @@ if __name__ == "__main__":
     args = ap.parse_args()
     variant = load_variant(args.variant) if args.variant else default_variant(env=args.env, seed=args.seed,
                                                                               batch_size=args.batch_size)
-    experiment(variant, log_dir=args.log_dir, seed=args.seed, num_epochs=args.epochs)
+    run_dir = None
+    if args.log_dir:
+        # the reference's run-directory layout (rlkit setup_logger, observed under runs/):
+        #   <log_dir>/<Prefix-with-dashes>/<prefix>_<timestamp>_0000--s-0/{variant.json, progress.csv}
+        import datetime
+        import json
+        ek = variant["expl_environment_kwargs"]
+        prefix = "{}_{}_{}_SEED{}".format(ek["env_name"], "".join(ek["robots"]), ek["controller"], args.seed)
+        stamp = datetime.datetime.now().strftime("%Y_%m_%d_%H_%M_%S")
+        run_dir = os.path.join(args.log_dir, prefix.replace("_", "-"), f"{prefix}_{stamp}_0000--s-0")
+        os.makedirs(run_dir, exist_ok=True)
+        json.dump(variant, open(os.path.join(run_dir, "variant.json"), "w"), indent=2, sort_keys=True)
+    experiment(variant, log_dir=run_dir, seed=args.seed, num_epochs=args.epochs)

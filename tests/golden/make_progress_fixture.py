@@ -27,8 +27,9 @@ for run, act_dim in RUNS.items():
                 break
             rows.append({k: float(v) for k, v in row.items()
                          if k.startswith("trainer/") or k.startswith("replay_buffer/") or k == "Epoch"})
+    header = open(path).readline().strip().split(",")
     out[run] = dict(act_dim=act_dim, trainer_kwargs=var["trainer_kwargs"],
-                    batch_size=var["algorithm_kwargs"]["batch_size"], rows=rows)
+                    batch_size=var["algorithm_kwargs"]["batch_size"], rows=rows, header=header)
 # global scan: Policy log std Max never above 2.0 (KA4), final buffer size (KA5)
 mx = -1e9
 sat = 0

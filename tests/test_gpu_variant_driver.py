@@ -26,11 +26,14 @@ def test_lift_seed17_variant_runs_unchanged(tmp_path):
     assert rows[0]["trainer/Alpha"] == pytest.approx(ka[0]["trainer/Alpha"], abs=1e-7)
     assert rows[0]["trainer/Alpha Loss"] == 0.0
     assert rows[0]["exploration/num paths total"] == 12 and rows[0]["evaluation/num paths total"] == 5
-    # epoch 1 logs the first step of the second training block: 1000 steps later alpha has decayed
-    assert rows[1]["trainer/Alpha"] < 0.5
+    # epoch 1 logs the first step of the second training block.  While log_pi stays far above the target
+    # entropy the alpha gradient keeps its sign and Adam moves log_alpha by ~lr per step, so alpha after
+    # 1001 steps is ~exp(-1.0): the shipped run logged the same value (KA2 over a whole block)
+    assert rows[1]["trainer/Alpha"] == pytest.approx(ka[1]["trainer/Alpha"], rel=0.02)
     assert os.path.exists(tmp_path / "progress.csv")
     header = open(tmp_path / "progress.csv").readline().strip().split(",")
-    assert header[0] == "replay_buffer/size" and header[-1] == "Epoch"
+    # column names AND order of the shipped progress.csv (notebooks/create_plots.ipynb keeps working)
+    assert header == json.load(open(os.path.join(GOLD, "progress_known_answers.json")))["Lift-Panda-OSC-POSE-SEED17"]["header"]
 
 
 def test_fused_loop_and_stepwise_driver_agree_on_the_logged_row():
