@@ -16,20 +16,22 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def test_lift_seed17_variant_runs_unchanged(tmp_path):
     v = variant.load_variant(os.path.join(GOLD, "Lift-Panda-OSC-POSE-SEED17.variant.json"))
-    rows = experiment(v, log_dir=str(tmp_path), seed=17, num_epochs=2, quiet=True)
+    rows = experiment(v, log_dir=str(tmp_path), seed=17, num_epochs=4, quiet=True)
     ka = json.load(open(os.path.join(GOLD, "progress_known_answers.json")))["Lift-Panda-OSC-POSE-SEED17"]["rows"]
     # every column of the shipped header that belongs to the hot path, same names
     for col in ka[0]:
         assert col in rows[0], col
     # KA5: buffer size 3300 + 2500*(e+1); KA1: alpha / alpha loss of the first train step ever
-    assert [r["replay_buffer/size"] for r in rows] == [5800, 8300]
+    assert [r["replay_buffer/size"] for r in rows] == [5800, 8300, 10800, 13300]
     assert rows[0]["trainer/Alpha"] == pytest.approx(ka[0]["trainer/Alpha"], abs=1e-7)
     assert rows[0]["trainer/Alpha Loss"] == 0.0
     assert rows[0]["exploration/num paths total"] == 12 and rows[0]["evaluation/num paths total"] == 5
     # epoch 1 logs the first step of the second training block.  While log_pi stays far above the target
     # entropy the alpha gradient keeps its sign and Adam moves log_alpha by ~lr per step, so alpha after
     # 1001 steps is ~exp(-1.0): the shipped run logged the same value (KA2 over a whole block)
-    assert rows[1]["trainer/Alpha"] == pytest.approx(ka[1]["trainer/Alpha"], rel=0.02)
+    for e, tol in ((1, 0.02), (2, 0.02), (3, 0.10)):          # shipped: 0.3675, 0.1352, 0.0497
+        # (by epoch 3 the policy's entropy -- hence the gradient's size -- depends on the environment)
+        assert rows[e]["trainer/Alpha"] == pytest.approx(ka[e]["trainer/Alpha"], rel=tol), e
     assert os.path.exists(tmp_path / "progress.csv")
     header = open(tmp_path / "progress.csv").readline().strip().split(",")
     # column names AND order of the shipped progress.csv (notebooks/create_plots.ipynb keeps working)
