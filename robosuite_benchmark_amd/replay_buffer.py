@@ -26,7 +26,7 @@ class EnvReplayBuffer:
     ``seed_from_numpy()`` after ``np.random.seed`` (scripts/train.py:112) or ``seed(int)``."""
 
     def __init__(self, max_replay_buffer_size, env=None, env_info_sizes=None, obs_dim=None, action_dim=None,
-                 device=0):
+                 device=0, numpy_global_stream=False):
         if env is not None:
             obs_dim = _space_dim(env.observation_space)
             action_dim = _space_dim(env.action_space)
@@ -35,6 +35,10 @@ class EnvReplayBuffer:
         self.env = env
         self._observation_dim, self._action_dim = int(obs_dim), int(action_dim)
         self._max_replay_buffer_size = int(max_replay_buffer_size)
+        # True: every random_batch() continues the process-wide np.random stream (adopts its state, samples on
+        # the device, writes the advanced state back) -- exactly what rlkit's np.random.randint call does, so
+        # host consumers of np.random (env resets, exploration noise) interleave identically.
+        self.numpy_global_stream = bool(numpy_global_stream)
         self._lib = _lib.load()
         h = C.c_void_p()
         _lib.check(self._lib.sac_buffer_create(C.byref(h), self._max_replay_buffer_size, self._observation_dim,
@@ -110,8 +114,12 @@ class EnvReplayBuffer:
         act = np.empty((B, A), np.float32)
         rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
         idx = np.empty(B, np.int64)
+        if self.numpy_global_stream:
+            self.seed_from_numpy()
         _lib.check(self._lib.sac_random_batch(self._h, B, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
                                               _lib.ptr(term), _lib.ptr(nobs), _lib.ptr(idx)), "sac_random_batch")
+        if self.numpy_global_stream:
+            self.sync_to_numpy()
         batch = dict(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs)
         return (batch, idx) if return_indices else batch
 

@@ -150,3 +150,19 @@ def test_device_batched_gather_matches_per_call_batches():
         i = want_idx[s]
         assert_batch_equal(got, dict(observations=host._obs[i], actions=host._act[i], rewards=host._rew[i],
                                      terminals=host._term[i], next_observations=host._next_obs[i]))
+
+
+def test_numpy_global_stream_mode_interleaves_with_host_consumers():
+    """Drop-in mode: random_batch continues np.random itself, so host draws in between stay coherent."""
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    obs, act, rew, term, nobs = synth_transitions(3000, 5, 2, seed=2)
+    dev = EnvReplayBuffer(3000, obs_dim=5, action_dim=2, numpy_global_stream=True)
+    dev.add_block(obs, act, rew, nobs, term)
+    np.random.seed(83)
+    ref = np.random.RandomState(83)
+    for B in (16, 128, 64):
+        host_draw = np.random.uniform(size=3)                  # e.g. an env reset between training steps
+        assert np.array_equal(host_draw, ref.uniform(size=3))
+        _, idx = dev.random_batch(B, return_indices=True)
+        assert np.array_equal(idx, ref.randint(0, 3000, B))
+    assert np.array_equal(np.random.randint(0, 10, 5), ref.randint(0, 10, 5))
