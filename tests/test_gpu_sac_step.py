@@ -36,8 +36,11 @@ def scale_err(got, want):
     return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(1e-30, np.max(np.abs(want))))
 
 
+# batch sizes cover every column split of the hidden layers: SP = 4 (B <= 256), 2 (B <= 512 and odd
+# row-block counts above), 1 (B >= 528 with an even row-block count)
 CASES = [("Lift", 128, 0.0), ("Lift", 256, 0.0), ("Door", 1024, 0.0), ("TwoArmLift", 256, 0.0),
-         ("Lift", 256, 0.05), ("Wipe", 128, 0.0), ("Lift", 16, 0.0)]
+         ("Lift", 256, 0.05), ("Wipe", 128, 0.0), ("Lift", 16, 0.0), ("Lift", 512, 0.0), ("Lift", 560, 0.0),
+         ("Stack", 48, 0.1)]
 
 
 @pytest.mark.parametrize("task,B,term_frac", CASES)
