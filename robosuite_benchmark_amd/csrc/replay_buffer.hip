@@ -150,6 +150,23 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
     const int ra = (tid < RB * ac) ? tid / ac : -1, qa = (tid < RB * ac) ? tid - ra * ac : 0;
     const int rs = (tid < 2 * RB) ? (tid & (RB - 1)) : -1;         // tid < 16: reward, 16..31: terminal
 
+    // The element -> (row, column) maps of the write-out are the same for every block: for narrow rows
+    // (NIT == 1: one pass per thread) they are computed once, outside the block loop (the integer
+    // divisions by the runtime row length otherwise dominate the write-out's instruction count).
+    int mo[4] = {0, 0, 0, 0}, ma[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
+    const bool has_o = tid < ((RB * O) >> 2), has_a = tid < ((RB * A) >> 2), has_s = tid < (O + A) * 4;
+    if constexpr (NIT == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int eo = 4 * tid + j, ro_ = eo / O;
+            mo[j] = has_o ? ro_ * Ost + (eo - ro_ * O) : 0;
+            const int ea = 4 * tid + j, ra_ = ea / A;
+            ma[j] = has_a ? ra_ * Ast + (ea - ra_ * A) : 0;
+            const int f = tid >> 2, r = 4 * (tid & 3) + j;
+            ms[j] = has_s ? ((f < O) ? r * Ost + f : 2 * RB * Ost + r * Ast + (f - O)) : 0;   // t_act follows t_nobs
+        }
+    }
+
     // stage C: registers of one block -> LDS tile -> slot
     auto write_out = [&](int blk, const float4 (&Do)[NIT], const float4 (&Dn)[NIT], const float4 &Da, float Ds,
                          float Ds2) {
@@ -165,6 +182,27 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
         if (ra >= 0) *reinterpret_cast<float4 *>(t_act + ra * Ast + 4 * qa) = Da;
         if (rs >= 0) S[(tid < RB ? L.off_rew : L.off_term) + row0 + rs] = (tid < RB) ? Ds : Ds2;
         lds_barrier();
+        if constexpr (NIT == 1) {
+            if (has_o) {
+                float4 a, b;
+                a.x = t_obs[mo[0]]; a.y = t_obs[mo[1]]; a.z = t_obs[mo[2]]; a.w = t_obs[mo[3]];
+                b.x = t_nobs[mo[0]]; b.y = t_nobs[mo[1]]; b.z = t_nobs[mo[2]]; b.w = t_nobs[mo[3]];
+                *reinterpret_cast<float4 *>(S + L.off_obs + (int64_t)row0 * O + 4 * tid) = a;
+                *reinterpret_cast<float4 *>(S + L.off_nobs + (int64_t)row0 * O + 4 * tid) = b;
+            }
+            if (has_a) {
+                float4 a;
+                a.x = t_act[ma[0]]; a.y = t_act[ma[1]]; a.z = t_act[ma[2]]; a.w = t_act[ma[3]];
+                *reinterpret_cast<float4 *>(S + L.off_act + (int64_t)row0 * A + 4 * tid) = a;
+            }
+            if (write_saT && has_s) {
+                float4 v;
+                v.x = lds[ms[0]]; v.y = lds[ms[1]]; v.z = lds[ms[2]]; v.w = lds[ms[3]];
+                *reinterpret_cast<float4 *>(S + L.off_saT + (int64_t)(tid >> 2) * B + row0 + 4 * (tid & 3)) = v;
+            }
+            lds_barrier();                         // tile free for the next block
+            return;
+        }
         {   // LDS -> contiguous row-major slot (16*O floats = 64*O bytes, 16-B aligned)
             float *dst = S + L.off_obs + (int64_t)row0 * O;
             float *dstn = S + L.off_nobs + (int64_t)row0 * O;
