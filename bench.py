@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--task", type=str, default=None,
                     help="N=1 only: another task of the sweep table (e.g. Door, TwoArmHandoff); default Lift")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", type=str, default="nccl", help="collective backend for N>1 (nccl == RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
     ap.add_argument("--profile-steps", type=int, default=500)
     args = ap.parse_args()
 
@@ -167,7 +170,9 @@ def main():
     import torch
     dist = None
     if world > 1:
-        dist = parallel.init_process_group("nccl", local_rank)      # nccl == RCCL on ROCm
+        dist = parallel.init_process_group(args.backend, local_rank)   # nccl == RCCL on ROCm
+    if args.single_device:
+        local_rank = 0
 
     task, O, A, seed = parallel.task_for_rank(rank, sweep=args.sweep and world > 1)
     if args.task is not None and world == 1:
