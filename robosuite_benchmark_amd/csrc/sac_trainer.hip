@@ -931,6 +931,10 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             for (int q = 0; q < (int)(sizeof(DwLayer) / 8); ++q) ud.w[q] = src[q];
         }
         const DwLayer &J = ud.J;
+#ifdef SAC_STAMPS
+        { unsigned long long probe = ud.w[0]; asm volatile("" :: "s"(probe)); }
+        STAMP(4, 3);
+#endif
         const int jj = blockIdx.x - J.job0;
         const int n0 = 16 * (jj / J.nk), k0 = 64 * (jj % J.nk);
         // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
@@ -983,6 +987,10 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             pb = J.bias[n]; mbv = J.mb[n]; vbv = J.vb[n];
             if (polyak) tbv = J.Tbias[n];
         }
+#ifdef SAC_STAMPS
+        { float probe = a[0][0] + b[3][3][3]; asm volatile("" :: "v"(probe)); }
+        STAMP(4, 4);
+#endif
         for (int sI = s0; sI < s1; sI += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
