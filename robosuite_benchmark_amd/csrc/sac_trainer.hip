@@ -40,11 +40,6 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 constexpr float ADAM_1MB1 = (float)(1.0 - 0.9), ADAM_1MB2 = (float)(1.0 - 0.999);
 constexpr int DIAG_TRACE_CAP = 4096;
 constexpr int RD = 4;             // ring depth (k-chunks in flight) for the runtime-K first layers
-#ifndef SAC_RDH
-#define SAC_RDH 4
-#endif
-constexpr int RDH4 = SAC_RDH;     // hidden layers' ring depth (measured: 4 > 16; the weight stream is bound by the
-                                  // per-CU fill rate from the Infinity Cache, not by exposed latency)
 
 // Step counters are HOST state passed as launch arguments (a device-side counter would put a
 // dependent, wave-uniform load -- readfirstlane + vmcnt(0) -- in front of every kernel's first
@@ -191,20 +186,10 @@ __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4
 // Weight stream of one wave: NT column tiles of 16 outputs, k-chunks of 16 held in a D-deep
 // register ring.  W is [n][ldw] (ldw % 4 == 0); lane (c = lane&15, g = lane>>4) loads the 16 B
 // W[n0_t + c][16 S + 4 g .. +3], i.e. lane group g owns contraction index k = 16S + 4g + i.
-#ifndef SAC_ROT
-#define SAC_ROT(b) (((b) >> 3) * 4)      // blocks b, b+8, ... usually share an XCD (speed only)
-#endif
-#define CHUNK_STRIDE 16
 template <int NT, int D = RD>
 struct WRing {
     f32x4 b[D][NT];
     const float *wp[NT];
-    int rot = 0, rmask = 0;          // chunk S is fetched as (S + rot) & rmask when rmask != 0
-    // Workgroups that share a weight matrix on one XCD start their sweep at different k-chunks: each
-    // line is then missed (Infinity-Cache latency) by one of them and L2-hit by the others, instead of
-    // every workgroup waiting on the same in-flight fills.  Any order of the contraction is valid.
-    __device__ __forceinline__ void rotate(int r, int KS) { rot = r & (KS - 1); rmask = KS - 1; }
-    __device__ __forceinline__ int chunk(int S) const { return rmask ? ((S + rot) & rmask) : S; }
     __device__ __forceinline__ void init(const float *W, int ldw, int n_base, int n_stride, int s_off = 0) {
         const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -216,7 +201,7 @@ struct WRing {
         for (int u = 0; u < D; ++u)
             if (u < KS) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + CHUNK_STRIDE * chunk(u));
+                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 16 * u);
             }
     }
 };
@@ -230,7 +215,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
-    f32x4 a_cur = ld4(xrow + 4 * ((4 * (R.chunk(0) + s_off) + g) ^ r));
+    f32x4 a_cur = ld4(xrow + 4 * ((4 * s_off + g) ^ r));
     for (int S0 = 0; S0 < KS; S0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
@@ -239,14 +224,14 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 // next chunk's A fragment (LDS) and the refill of this ring slot (global) are issued
                 // BEFORE this chunk's 4*NT MFMAs and may not sink below them
                 const int Sn = (S + 1 < KS) ? S + 1 : S;
-                const f32x4 a_nxt = ld4(xrow + 4 * ((4 * (R.chunk(Sn) + s_off) + g) ^ r));
+                const f32x4 a_nxt = ld4(xrow + 4 * ((4 * (Sn + s_off) + g) ^ r));
                 f32x4 bc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bc[t] = R.b[u][t];
 #ifndef SAC_ABLATE_LOADS
                 if (S + D < KS) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + CHUNK_STRIDE * R.chunk(S + D));
+                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 16 * (S + D));
                 }
 #endif
                 SB();
@@ -1414,9 +1399,8 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     SAC_HIP(hipStreamSynchronize(s));      // hl is a local
     t->dw.L = t->d_dwl;
 
-    const int KL0p = round_up(t->KP, 64), KL0q = round_up(t->KQ, 64);
+    const int KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
-    (void)KL0p;
     const int sw = 64 * (4 / t->SP);
     t->lds_fa = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 4 * nth * 256);
     t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 64);
