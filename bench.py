@@ -39,9 +39,8 @@ def flops_per_kernel(B, O, A):
     Q = (O + A) * H + H * H + H                # Q MACs / sample
     return {
         "k_fwd_a": 2 * B * (2 * P + 2 * Q),                              # pi(s), pi(s'), Q1/Q2(s,a)
-        "k_fwd_b": 2 * B * 4 * Q,                                        # Q1/Q2(s,a_new), T1/T2(s',a')
-        "k_q_bwd": 2 * B * (2 * (H + H * H) + 2 * (H + H * H + A * H)),  # critic dX (2 nets) + actor dX (2 nets)
-        "k_policy_bwd": 2 * B * (2 * A * H + H * H),                     # head^T, fc1^T
+        "k_fwd_b": 2 * B * (4 * Q + 2 * (H + H * H + A * H)),            # Q1/Q2(s,a_new), T1/T2(s',a') + actor dX (2 nets)
+        "k_bwd": 2 * B * (2 * (H + H * H) + 2 * A * H + H * H),          # critic dX (2 nets) | policy head^T, fc1^T
         "k_dw_adam": 2 * B * (2 * Q + P),                                # dW of two critics + policy
     }
 

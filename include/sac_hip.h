@@ -164,9 +164,9 @@ int sac_sync(sac_trainer_t *t);
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms);
 
 /* profiling pass: the same loop with HIP events (on the launching streams) around every kernel.
- * out_ms[9] = {index kernel, gather kernel, then the MEAN per-launch ms of k_fwd_a, k_fwd_b, k_q_bwd,
- * k_policy_bwd, k_dw_adam (each minus the cost of an empty event pair), that empty-pair cost, and
- * the wall ms of all n_steps steps}.  n_steps <= 4096. */
+ * out_ms[9] = {index kernel, gather kernel, then the MEAN per-launch ms of k_fwd_a, k_fwd_b, k_bwd,
+ * a reserved slot (0), k_dw_adam (each minus the cost of an empty event pair), that empty-pair cost,
+ * and the wall ms of all n_steps steps}.  n_steps <= 4096. */
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float out_ms[9]);
 
 /* test access to intermediates of the last step: name in {"a_new","log_pi","mu","log_std","q1","q2",

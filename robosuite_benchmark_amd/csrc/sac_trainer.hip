@@ -1,4 +1,4 @@
-// SAC gradient step on MI355X (gfx950): five row-block / tile-owner kernels per step.
+// SAC gradient step on MI355X (gfx950): four row-block / tile-owner kernels per step.
 //
 // Replaces rlkit SACTrainer.train_from_torch (+ np_to_pytorch_batch, soft_update_from_to); call
 // sites /root/reference/util/rlkit_utils.py:64-106, /root/reference/util/rlkit_custom.py:238.
@@ -12,10 +12,10 @@
 // the Polyak update in its epilogue, so gradients never round-trip through HBM.
 //
 //   A k_fwd_a       16*B/16 WGs   pi(s), pi(s') -> head partials; Q1,Q2(s,a) -> q partials
-//   B k_fwd_b       16*B/16 WGs   tanh-Gaussian head, alpha step; Q1,Q2(s,a_new), T1,T2(s',a') -> q partials
-//   C k_q_bwd       16*B/16 WGs   critic dL/dh (2 nets), actor dQ/da partials (2 nets)
-//   D k_policy_bwd   4*B/16 WGs   head gradient (reparameterised), dL/dh
-//   E k_dw_adam     ~250  WGs     dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
+//   B k_fwd_b       16*B/16 WGs   tanh-Gaussian head; Q1,Q2(s,a_new), T1,T2(s',a') -> q partials;
+//                                 Q1,Q2(s,a_new) blocks continue to the UNIT gradient dQ/da (partials)
+//   C k_bwd         12*B/16 WGs   critic dL/dh (2 nets) | policy: min-select, head gradient (reparameterised), dL/dh
+//   D k_dw_adam     ~250  WGs     dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
 // (every 256-wide layer is split over 4 workgroups per 16-row block; partial sums meet at launch boundaries)
 //
 // Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round
@@ -209,9 +209,16 @@ struct WRing {
 // acc[t] += X[16 x 16*KS] * W_t^T.  X: LDS row-block, row stride KL (multiple of 64), 16-B chunks
 // XOR-swizzled by row (conflict-free ds_read_b128 for the MFMA A operand).  The ring must have been
 // fill()ed; chunk S+RD is requested as soon as chunk S has been copied out.
-template <int NT, int D>
+// `stage` != null: every weight fragment is also copied to LDS as it leaves the ring, TRANSPOSED: stage[k][row of W]
+// with row stride WLD (this wave's tile t owns columns 16 t ..), for a later contraction over the rows of W
+// (gemm_lds_rows) -- the same bytes a backward pass would otherwise fetch again from the transposed copy.
+#ifndef SAC_STAGE
+#define SAC_STAGE 1
+#endif
+constexpr int WLD = 64 + 4;       // 64 staged weight rows; +4: scatter writes and 16-B reads are bank-conflict free
+template <bool STAGED = false, int NT, int D>
 __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
-                                          int s_off = 0) {
+                                          int s_off = 0, float *stage = nullptr) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
@@ -228,6 +235,12 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 f32x4 bc[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) bc[t] = R.b[u][t];
+                if constexpr (STAGED) {     // (compile-time: a run-time test here made hipcc mis-order the MFMAs' waits)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) stage[(16 * S + 4 * g + i) * WLD + 16 * t + r] = bc[t][i];
+                }
 #ifndef SAC_ABLATE_LOADS
                 if (S + D < KS) {
 #pragma unroll
@@ -251,6 +264,29 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
             }
         }
     }
+}
+
+// acc[t] += X[16 x 16*KS] * W[16*KS rows][16 columns at col0 + 16 t] from the slice staged by gemm_ring
+// (WL[column][row]): contraction over the ROWS of W, lane group g owns rows 16S + 4g + i like everywhere else,
+// so a lane's four B values are one 16-B LDS read.  All KS*NT fragments are read before the first MFMA.
+template <int NT, int KS>
+__device__ __forceinline__ void gemm_lds_rows(const float *WL, int col0, const float *X, int KL, f32x4 (&acc)[NT]) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const float *xrow = X + r * KL;
+    f32x4 a[KS], bf[KS][NT];
+#pragma unroll
+    for (int S = 0; S < KS; ++S) {
+        a[S] = ld4(xrow + 4 * ((4 * S + g) ^ r));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bf[S][t] = ld4(WL + (col0 + 16 * t + r) * WLD + 16 * S + 4 * g);
+    }
+#pragma unroll
+    for (int S = 0; S < KS; ++S)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[S][i], bf[S][t][i], acc[t], 0, 0, 0);
 }
 
 // First layers (K = obs or obs+act, a few k-chunks): every chunk was requested by fill(), nothing is
@@ -386,11 +422,12 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
 // consumer -- always the next launch -- adds the four partials in a fixed order.
 //
 //   A k_fwd_a   16*B/16 WGs  pi(s), pi(s') -> head partials;   Q1,Q2(s,a) -> q partials
-//   B k_fwd_b   16*B/16 WGs  tanh-Gaussian head (from the partials), alpha step (last arriver);
-//                            Q1,Q2(s,a_new), T1,T2(s',a') -> q partials
-//   C k_q_bwd   16*B/16 WGs  q = sum of partials; critic dL/dh (kept for dW), actor d/da partials
-//   D k_pi_bwd   4*B/16 WGs  head gradient (reparameterised, analytic), dL/dh
-//   E k_dw_adam              (below)
+//   B k_fwd_b   16*B/16 WGs  tanh-Gaussian head (from the partials); Q1,Q2(s,a_new), T1,T2(s',a') -> q partials;
+//                            the Q(s,a_new) blocks go on to the unit input gradient dQ_i/da (partials): the chain
+//                            is linear in dq, so the min over the twins can be applied by the consumer
+//   C k_bwd     12*B/16 WGs  q = sum of partials; critic dL/dh (kept for dW) | policy head gradient
+//                            (reparameterised, analytic) from sum_i dq_i * dQ_i/da, dL/dh
+//   D k_dw_adam              (below)
 // ------------------------------------------------------------------------------------------
 // SP = column split of the 256-wide layers (4, 2 or 1 workgroups per row-block), NTW = 4 / SP tiles per wave.
 // Small batches want SP = 4 (more CUs, 64 KB of weights each); B >= 512 already fills the chip with
@@ -517,7 +554,9 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     float *XQ = lds;                     // [16][KLQ]  cat(obs, action)
     float *X1 = XQ + RB * KLQ;           // [16][256]
     float *XS = X1 + RB * H;             // [16][SW]
-    float *red = XS + RB * SW;           // 64 floats
+    float *red = XS + RB * SW;           // 1024 floats (split-K scratch of the actor tail)
+    constexpr bool STAGE = (SP == 4) && SAC_STAGE;    // 64-row weight slice (66.5 KB) fits LDS: the actor tail reads it from there
+    float *WL = red + 1024;              // [256][WLD]  (STAGE only)
     // XCD-aware map (see k_fwd_a): b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> T1, {6,7} -> T2
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
     const int p4 = xr >> 1;                                          // Q1, Q2 on (s,a_new); T1, T2 on (s',a')
@@ -620,11 +659,27 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         float *h1T = (p4 < 2) ? d.QH1T + (size_t)pass * H * B : nullptr;
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
     }
+    // Q1/Q2(s,a_new) blocks go on to the actor's input gradient (below): request its weights now (the first
+    // layer's ring registers are free), so they arrive under the 256x256 slice.
+    WRing<STAGE ? 1 : 4, STAGE ? 1 : 4> rw;                  // W2^T: all 256 first-hidden features x this block's columns
+    WRing<1, 4> ra;                                          // W1^T action rows: this wave's 64 first-hidden features
+    if (p4 < 2) {
+        SB();
+        const float *PT = d.PT[1 + p4];
+        if constexpr (!STAGE) {
+            rw.init(PT + d.LQ[1].offWt, H, 64 * wave, 16, 4 * NTW * part);
+            rw.fill(4 * NTW);
+        }
+        ra.init(PT + d.LQ[0].offWt + (size_t)O * H, H, 0, 16, 4 * wave);
+        ra.fill(4);
+        SB();
+    }
     lds_barrier();
     STAMP(1, 3);
     {
         f32x4 acc[NTW] = {};
-        gemm_ring(r1, X1, H, H >> 4, acc);
+        if (STAGE && p4 < 2) gemm_ring<true>(r1, X1, H, H >> 4, acc, 0, WL + 16 * NTW * wave);
+        else gemm_ring(r1, X1, H, H >> 4, acc);
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
@@ -635,53 +690,81 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     s = group16_sum(s);
     if (a == 0) d.qpart[((size_t)pass * SP + part) * B + grow] = s;
     STAMP(1, 4);
+    if (p4 >= 2) return;
+    // ---- actor path: UNIT input gradient of Q_i(s, a_new) (dq = 1), partial over this block's columns ----
+    // The chain dq -> dh2 -> dh1 -> da is linear in the per-row scalar dq = -sel/B, which needs min(Q1, Q2),
+    // i.e. the sum of all partial q's: the policy-backward blocks of the next launch apply it to the sum of
+    // these partials.  Everything else the chain needs is already in this block's LDS.
+#pragma unroll
+    for (int u = 0; u < 4 * NTW; ++u) {                      // dq/dh2 = w3 * relu'(h2), in place (own elements)
+        const int off = lds_off(row, a + 16 * u, SW);
+        XS[off] = (XS[off] > 0.f) ? w3[u] : 0.f;
+    }
+    lds_barrier();
+    STAMP(1, 5);
+    {   // partial dq/dh1 over ALL first-hidden features = dq/dh2[:, slice] . W2[slice, :], masked in place
+        f32x4 acc[4] = {};
+        if constexpr (STAGE) gemm_lds_rows<4, 4 * NTW>(WL, 64 * wave, XS, SW, acc);
+        else gemm_ring(rw, XS, SW, 4 * NTW, acc);
+        const int g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int off = lds_off(4 * g + i, 64 * wave + 16 * t + c, H);
+                X1[off] = (X1[off] > 0.f) ? acc[t][i] : 0.f;
+            }
+        }
+    }
+    lds_barrier();
+    STAMP(1, 6);
+    {   // partial dq/da = dq/dh1 . W1[:, O:O+A]  (contraction split over the waves)
+        f32x4 acc[1] = {};
+        gemm_ring(ra, X1, H, 4, acc, 4 * wave);
+        splitk_reduce<1>(acc, nullptr, red, d.dapart + (((size_t)p4 * SP + part) * B + row0) * 16, 16);
+    }
+    STAMP(1, 7);
 }
 
 // ------------------------------------------------------------------------------------------
-// C: Q backward.  critic Q1/Q2 (dL/dh kept for dW) and the actor path through Q1/Q2 down to
-// d/da_new (input gradient only; partial over this block's first-layer features).
+// C k_bwd: the two critic backward passes (dL/dh kept for dW) and the policy backward, side by side.
+// Both depend only on launch B (q partials, sum(log_pi) partials, unit d/da partials).
 // ------------------------------------------------------------------------------------------
+// critic Q_i(s,a): y, dq = 2(q - y)/B, dL/dh2 (all features, recomputed by the SP blocks), dL/dh1 (this
+// block's features)
 template <int SP>
-__global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+__device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__restrict__ S, const SlotLayout &SL,
+                                                 const StepArg &sa, int qi, int b) {
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, NB = d.NB;
-    float *X2 = lds;                 // dL/dh2 row-block [16][256] (recomputed by the SP blocks)
-    float *XS = X2 + RB * H;         // dL/dh1, this block's features [16][SW] (actor)
-    float *red = XS + RB * SW;       // 1024 floats
+    float *X2 = lds;                 // dL/dh2 row-block [16][256]
     __shared__ float s_dq[RB];
-    // XCD-aware map (see k_fwd_a): b % 8 in {0..3} -> twin Q1, {4..7} -> twin Q2
-    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
-    const int qi = xr >> 2;                // which twin
-    const int b = 4 * xq + (xr & 3);       // index inside the twin's 2*SP*NB blocks: critic first, then actor
-    const int part = b % SP, rb = (b / SP) % NB;
-    const bool critic = ((b / SP) / NB) == 0;
-    const int pass = (critic ? 0 : 2) + qi;
+    const int part = b % SP, rb = b / SP;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const float *P = d.P[1 + qi];
     const float *PT = d.PT[1 + qi];
     const float invB = 1.0f / (float)B;
-    const float *h2T = d.QH2T + (size_t)pass * H * B;
-    const float *h1T = d.QH1T + (size_t)pass * H * B;
+    const float *h2T = d.QH2T + (size_t)qi * H * B;
+    const float *h1T = d.QH1T + (size_t)qi * H * B;
     const int n0 = SW * part + 16 * NTW * wave;
     const long long oB3 = d.LQ[2].offB;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
-    const float b3a = sload(d.P[critic ? 3 : 1] + oB3), b3b = sload(d.P[critic ? 4 : 2] + oB3), b3q = sload(P + oB3);
+    const float b3a = sload(d.P[3] + oB3), b3b = sload(d.P[4] + oB3), b3q = sload(P + oB3);
     float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;      // loads only: no use before SB
 #pragma unroll
     for (int p = 0; p < SP; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
-        const int pa = critic ? 4 : 2, pb = critic ? 5 : 3;
 #pragma unroll
         for (int p = 0; p < SP; ++p) {
-            qa[p] = d.qpart[((size_t)pa * SP + p) * B + r];
-            qb[p] = d.qpart[((size_t)pb * SP + p) * B + r];
-            if (critic) qq[p] = d.qpart[((size_t)qi * SP + p) * B + r];
+            qa[p] = d.qpart[((size_t)4 * SP + p) * B + r];
+            qb[p] = d.qpart[((size_t)5 * SP + p) * B + r];
+            qq[p] = d.qpart[((size_t)qi * SP + p) * B + r];
         }
-        if (critic) { in_c = d.logpi2[r]; in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r]; }
+        in_c = d.logpi2[r]; in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
     }
     const int k = threadIdx.x;
     const float wk = P[d.LQ[2].offW + k];
@@ -696,11 +779,6 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
     f32x4 h1v[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) h1v[t] = ld4(h1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
-    WRing<1, NTW> ra;
-    if (!critic) {
-        ra.init(PT + d.LQ[0].offWt + (size_t)d.O * H, H, 0, 16, 4 * NTW * part + NTW * wave);
-        ra.fill(NTW);
-    }
     SB();
     // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
     const float alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
@@ -712,31 +790,23 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         float va = qa[0], vb = qb[0], vq = qq[0];
 #pragma unroll
         for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; vq += qq[p]; }      // fixed order
-        va += b3a;                                                       // T1 (critic) / Q1(s,a_new) (actor)
-        vb += b3b;                                                       // T2          / Q2(s,a_new)
-        float dq;
-        if (critic) {
-            vq += b3q;                                                   // Q_i(s,a)
-            const float tq = fminf(va, vb) - alpha * in_c;
-            const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
-            dq = 2.0f * (vq - yv) * invB;
-            if (part == 0) {
-                d.q[(size_t)qi * B + r] = vq;
-                d.dq16T[(size_t)qi * 16 * B + r] = dq;                  // row 0 of the padded [16][B]
-                if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
-            }
-        } else {
-            const float mine = qi ? vb : va, other = qi ? va : vb;
-            const float sel = (mine < other) ? 1.0f : ((mine == other) ? 0.5f : 0.0f);   // torch.min backward
-            dq = -invB * sel;
-            if (part == 0 && qi == 0) { d.q[2 * (size_t)B + r] = va; d.q[3 * (size_t)B + r] = vb; }
+        va += b3a;                                                       // T1(s',a')
+        vb += b3b;                                                       // T2(s',a')
+        vq += b3q;                                                       // Q_i(s,a)
+        const float tq = fminf(va, vb) - alpha * in_c;
+        const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
+        const float dq = 2.0f * (vq - yv) * invB;
+        if (part == 0) {
+            d.q[(size_t)qi * B + r] = vq;
+            d.dq16T[(size_t)qi * 16 * B + r] = dq;                      // row 0 of the padded [16][B]
+            if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
         }
         s_dq[threadIdx.x] = dq;
     }
     lds_barrier();
     // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner block
     {
-        float *outT = (critic && (k / SW) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
+        float *outT = ((k / SW) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             f32x4 gv;
@@ -757,49 +827,44 @@ __global__ __launch_bounds__(256) void k_q_bwd(Dev d, const float *__restrict__ 
         for (int t = 0; t < NTW; ++t) {
             f32x4 gv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
-                if (!critic) XS[lds_off(4 * g + i, 16 * (NTW * wave + t) + c, SW)] = gv[i];
-            }
-            if (critic) st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
+            for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
+            st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
         }
-    }
-    if (critic) return;
-    lds_barrier();
-    // partial d/da_new = dL/dh1[:, slice] . W1[slice, O:O+A]   -> dapart[qi][part][row][16]
-    {
-        f32x4 acc[1] = {};
-        gemm_ring(ra, XS, SW, NTW, acc, NTW * wave);
-        splitk_reduce<1>(acc, nullptr, red, d.dapart + (((size_t)qi * SP + part) * B + row0) * 16, 16);
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// D: policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient.
+// policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient.
+//   da         = sum_i dq_i * (unit d Q_i/da from launch B),  dq_i = -sel_i / B  (torch.min backward)
 //   dL/dz      = da*(1-a^2) + (alpha/B) * 2a(1-a^2)/(1-a^2+1e-6)
 //   dL/dmu     = dL/dz                      (the Normal terms cancel exactly under rsample)
 //   dL/dlogstd = dL/dz * std*eps - alpha/B  (masked by the clamp)
-// ------------------------------------------------------------------------------------------
 template <int NTH, int SP>
-__global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
+__device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa, int b) {
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, A = d.A;
     float *XH = lds;                 // [16][64] head gradient row-block
     float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the SP blocks)
-    const int part = blockIdx.x % SP, rb = blockIdx.x / SP, row0 = rb * RB;
+    const int part = b % SP, rb = b / SP, row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const float *PT = d.PT[0];
     const float invB = 1.0f / (float)B;
     const int n0 = SW * part + 16 * NTW * wave;
+    const long long oB3 = d.LQ[2].offB;
 
     // ---- up-front requests, in consumption order (vmcnt retires in issue order) ----
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15;
     const int gi = (row0 + row) * 16 + a;
-    float act = 0.f, dap[2 * SP], lsv = 0.f, epv = 0.f, okv = 0.f;      // loads only: no use before SB
+    const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
+    float act = 0.f, dap[2 * SP], qa[SP], qb[SP], lsv = 0.f, epv = 0.f, okv = 0.f;   // loads only: no use before SB
 #pragma unroll
     for (int p = 0; p < 2 * SP; ++p) dap[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < SP; ++p) {                           // Q1, Q2(s, a_new) partials of this row
+        qa[p] = d.qpart[((size_t)2 * SP + p) * B + row0 + row];
+        qb[p] = d.qpart[((size_t)3 * SP + p) * B + row0 + row];
+    }
     if (a < A) {
         act = d.anew[gi];
 #pragma unroll
@@ -828,19 +893,32 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
 #pragma unroll
     for (int p = 0; p < 2 * SP; ++p) USE_FROM_HERE(dap[p]);
-    if (a < A) {
-        float da1 = dap[0], da2 = dap[SP];
 #pragma unroll
-        for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }          // fixed order
-        const float om = 1.0f - act * act;
-        const float dz = (da1 + da2) * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
-        const float stdv = expf(lsv);
-        const float dls = (dz * stdv * epv - alpha * invB) * okv;
-        XH[lds_off(row, a, 64)] = dz;
-        XH[lds_off(row, A + a, 64)] = dls;
-        if (part == 0) {
-            d.dheadT[(size_t)a * B + row0 + row] = dz;
-            d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+    for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); }
+    {
+        float va = qa[0], vb = qb[0];
+#pragma unroll
+        for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; }                   // fixed order
+        va += b3a; vb += b3b;                                                        // Q1, Q2(s, a_new)
+        // torch.min backward: the smaller one takes the gradient, a tie splits it
+        const float sel1 = (va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f);
+        const float dq1 = -invB * sel1, dq2 = -invB * (1.0f - sel1);
+        if (part == 0 && a == 0) { d.q[2 * (size_t)B + row0 + row] = va; d.q[3 * (size_t)B + row0 + row] = vb; }
+        if (a < A) {
+            float da1 = dap[0], da2 = dap[SP];
+#pragma unroll
+            for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
+            const float da = da1 * dq1 + da2 * dq2;
+            const float om = 1.0f - act * act;
+            const float dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+            const float stdv = expf(lsv);
+            const float dls = (dz * stdv * epv - alpha * invB) * okv;
+            XH[lds_off(row, a, 64)] = dz;
+            XH[lds_off(row, A + a, 64)] = dls;
+            if (part == 0) {
+                d.dheadT[(size_t)a * B + row0 + row] = dz;
+                d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+            }
         }
     }
     lds_barrier();
@@ -871,6 +949,19 @@ __global__ __launch_bounds__(256) void k_policy_bwd(Dev d, StepArg sa) {
             st4(d.dPH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
         }
     }
+}
+
+// Block -> work map.  Three equal groups of SP*NB blocks: critic Q1, critic Q2, policy.  While they fit one
+// per CU on six XCDs (3*SP*NB <= 192) the map is XCD-aware (b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> policy,
+// {6,7} idle: an XCD's L2 pulls one network's transposed weights); larger batches use every CU instead.
+template <int NTH, int SP>
+__global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa, int compact) {
+    int cls, b;
+    if (compact) { cls = (blockIdx.x & 7) >> 1; b = 2 * (blockIdx.x >> 3) + (blockIdx.x & 1); }
+    else { cls = blockIdx.x % 3; b = blockIdx.x / 3; }
+    if (cls > 2) return;
+    if (cls < 2) critic_bwd_block<SP>(d, S, SL, sa, cls, b);
+    else policy_bwd_block<NTH, SP>(d, sa, b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1150,11 +1241,10 @@ struct sac_trainer {
     float last_ms[4] = {0, 0, 0, 0};
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
-    size_t lds_qb = 0, lds_pb = 0;
+    size_t lds_bw = 0;
     void (*fwd_a)(Dev, const float *, SlotLayout) = nullptr;
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
-    void (*q_bwd)(Dev, const float *, SlotLayout, StepArg) = nullptr;
-    void (*pi_bwd)(Dev, StepArg) = nullptr;
+    void (*bwd)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
     size_t lds_fa = 0, lds_fb = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
 };
@@ -1245,7 +1335,7 @@ int ensure_stage_t(sac_trainer *t, size_t bytes) {
     return 0;
 }
 
-// the five launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
+// the four launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
 // between the launches (profiling pass only)
 int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr) {
     const Dev &d = t->dev;
@@ -1259,10 +1349,9 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
-    hipLaunchKernelGGL(t->q_bwd, dim3(4 * SPv * NB), dim3(256), t->lds_qb, s, d, S, SL, sa);
-    if (ev) SAC_HIP(hipEventRecord(ev[3], s));
-    hipLaunchKernelGGL(t->pi_bwd, dim3(SPv * NB), dim3(256), t->lds_pb, s, d, sa);
-    if (ev) SAC_HIP(hipEventRecord(ev[4], s));
+    const int compact = (3 * SPv * NB <= 192) ? 1 : 0;     // see k_bwd
+    hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sa, compact);
+    if (ev) { SAC_HIP(hipEventRecord(ev[3], s)); SAC_HIP(hipEventRecord(ev[4], s)); }
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
     if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
     SAC_HIP(hipGetLastError());
@@ -1403,9 +1492,8 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     const int nth = t->NH / 16;
     const int sw = 64 * (4 / t->SP);
     t->lds_fa = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 4 * nth * 256);
-    t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 64);
-    t->lds_qb = sizeof(float) * (size_t)(RB * H + RB * sw + 1024);
-    t->lds_pb = sizeof(float) * (size_t)(RB * 64 + RB * H);
+    t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 1024 + (t->SP == 4 ? H * WLD : 0));
+    t->lds_bw = sizeof(float) * (size_t)(RB * 64 + RB * H);
     SAC_REQUIRE(t->lds_fa <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     const bool wide = t->KQ > 16 * RD0;
 #define SAC_PICK(SPV)                                                                                      \
@@ -1414,19 +1502,19 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
                               : (wide ? &k_fwd_a<2, true, SPV> : &k_fwd_a<2, false, SPV>);                  \
         t->fwd_b = (nth == 1) ? (wide ? &k_fwd_b<1, true, SPV> : &k_fwd_b<1, false, SPV>)                   \
                               : (wide ? &k_fwd_b<2, true, SPV> : &k_fwd_b<2, false, SPV>);                  \
-        t->q_bwd = &k_q_bwd<SPV>;                                                                          \
-        t->pi_bwd = (nth == 1) ? &k_policy_bwd<1, SPV> : &k_policy_bwd<2, SPV>;                            \
+        t->bwd = (nth == 1) ? &k_bwd<1, SPV> : &k_bwd<2, SPV>;                                             \
     } while (0)
     if (t->SP == 4) SAC_PICK(4);
     else if (t->SP == 2) SAC_PICK(2);
     else SAC_PICK(1);
 #undef SAC_PICK
-    if (t->lds_fa > 64 * 1024) {
+    if (t->lds_fa > 64 * 1024)
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fa));
+    if (t->lds_fb > 64 * 1024)
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_b),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fb));
-    }
+    SAC_REQUIRE(t->lds_fb <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     SAC_HIP(hipStreamSynchronize(s));
     *out = t;
     return 0;
@@ -1643,14 +1731,15 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
     if (stage_batches(t, b, n_steps)) return -1;
-    constexpr int NE = 7;            // e0 A e1 B e2 C e3 D e4 E e5 (nothing) e6
+    constexpr int NE = 7;            // e0 A e1 B e2 C e3 (nothing) e4 D e5 (nothing) e6
     std::vector<hipEvent_t> ev((size_t)n_steps * NE);
     for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
     for (int64_t i = 0; i < n_steps; ++i)
         if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * NE])) return -1;
     SAC_HIP(hipStreamSynchronize(s));
-    // interval k = launch k between two event records; the empty interval e4->e5 measures what an
-    // event pair costs by itself and is subtracted from the four kernel intervals
+    // interval k = launch k between two event records; the empty interval e5->e6 measures what an
+    // event pair costs by itself and is subtracted from the kernel intervals (slot 5 of out_ms, once
+    // k_policy_bwd, is the second empty interval and reads 0)
     double acc[NE - 1] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = 0; i < n_steps; ++i)
         for (int k = 0; k < NE - 1; ++k) {

@@ -151,7 +151,7 @@ class SACTrainer:
                    "sac_profile_loop")
         self._num_train_steps += int(n_steps)
         self._host_policy_stale = True
-        names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_q_bwd", "k_policy_bwd", "k_dw_adam",
+        names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_bwd", "reserved", "k_dw_adam",
                  "event_pair", "steps_wall"]
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
