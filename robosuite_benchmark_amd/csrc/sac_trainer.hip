@@ -157,6 +157,23 @@ __device__ __forceinline__ T sload(const T *p) {
 }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 
+// Kernel arguments are ~0.7 KB (11 scalar-cache lines) and hipcc loads them lazily -- an s_load right
+// before each first use, each followed by s_waitcnt lgkmcnt(0): a chain of serial misses (the scalar cache is
+// invalidated at every dispatch) worth 2-3 us in front of the prologue's loads.  Touching one dword per 64-B
+// line at entry turns that into ONE round trip; the lazy loads then hit the scalar cache.
+template <int NBYTES>
+__device__ __forceinline__ void kernarg_prefetch() {
+    typedef const __attribute__((address_space(4))) int *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int NL = (NBYTES + 63) / 64;
+    static_assert(NL <= 16, "kernarg_prefetch: more than 16 lines");
+    int x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = ka[i < NL ? i * 16 : 0];
+    asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]), "s"(x[8]),
+                 "s"(x[9]), "s"(x[10]), "s"(x[11]), "s"(x[12]), "s"(x[13]), "s"(x[14]), "s"(x[15]));
+}
+
 // SURVEY Appendix A lines 4-6: alpha_loss = -mean(log_alpha * (log_pi + H)); one Adam step on log_alpha;
 // alpha = exp(log_alpha) (post-step).  sum(log_pi) arrives as NB per-row-block partials (written by the
 // previous launch); every workgroup that needs alpha recomputes this handful of scalar operations from the
@@ -195,6 +212,16 @@ struct WRing {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             wp[t] = W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
+    }
+    // chunks [u0, u1) of the first min(D, KS): the prologues issue a ring in pieces between independent
+    // work -- a wave whose loads outrun the CU's fill path (~20 B/clk) just stalls at issue
+    __device__ __forceinline__ void fill_part(int KS, int u0, int u1) {
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (u >= u0 && u < u1 && u < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 16 * u);
+            }
     }
     __device__ __forceinline__ void fill(int KS) {        // chunks 0 .. min(D, KS)-1 into flight
 #pragma unroll
@@ -311,6 +338,33 @@ __device__ __forceinline__ void gemm_straight(WRing<NT, D> &R, const float *X, i
         }
     }
 }
+// Same, with the NEXT layer's ring requested in four pieces behind the first four chunks' MFMAs: issued at entry
+// those loads would only keep the wave stalled at issue (the CU's fill path is the bottleneck) in front of this GEMM.
+template <int NT, int D, int NT1, int D1>
+__device__ __forceinline__ void gemm_straight_pf(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
+                                                 WRing<NT1, D1> &R1, int KS1) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const float *xrow = X + r * KL;
+    constexpr int Q1 = (D1 + 3) / 4;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        if (u < KS) {
+            const f32x4 a = ld4(xrow + 4 * ((4 * u + g) ^ r));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], R.b[u][t][i], acc[t], 0, 0, 0);
+            }
+        }
+        if (u < 4) {
+            SB();
+            R1.fill_part(KS1, u * Q1, (u + 1) * Q1);
+            SB();
+        }
+    }
+}
 constexpr int RD0 = 8;            // narrow first layers: up to 8 k-chunks (K <= 128) held at once
 
 // split-K epilogue: the four waves each hold a partial [16 x 16*NTT]; sum them through LDS into
@@ -362,32 +416,37 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 
 // swizzled LDS row-block [16][KL] from row-major global rows (two sources concatenated), in two
 // phases: issue() puts the loads in flight early, commit() writes LDS once they are needed.
+// Thread (row = tid / 16, p = tid % 16) owns columns p, p + 16, ... of its row: no division, and every
+// load is unconditional (clamped address + select) -- a conditional load is a branch whose merge waits.
 template <int ROWS_MAXE>                      // Kfill <= 16 * ROWS_MAXE
 struct RowRegs {
     float v[ROWS_MAXE];
     __device__ __forceinline__ void issue(int Kfill, const float *__restrict__ s0, int n0, int ld0,
                                           const float *__restrict__ s1, int n1, int ld1) {
         const int nper = Kfill >> 4;          // RB * Kfill / 256
+        const int row = threadIdx.x >> 4, p = threadIdx.x & 15;
+        const float *r0 = s0 + row * ld0;
+        const float *r1 = (n1 > 0 ? s1 + row * ld1 : r0) - (n1 > 0 ? n0 : 0);
 #pragma unroll
         for (int i = 0; i < ROWS_MAXE; ++i) {
             v[i] = 0.f;
             if (i < nper) {
-                const int e = threadIdx.x + 256 * i;
-                const int row = e / Kfill, k = e - row * Kfill;
-                if (k < n0) v[i] = s0[row * ld0 + k];
-                else if (k < n0 + n1) v[i] = s1[row * ld1 + (k - n0)];
+                const int k = p + 16 * i;
+                const float *src = (k < n0) ? r0 + k : ((k < n0 + n1) ? r1 + k : r0);
+                v[i] = *src;
             }
         }
     }
-    // columns [skip_lo, skip_hi) are left to another writer (the policy head's action)
-    __device__ __forceinline__ void commit(float *X, int KL, int Kfill, int skip_lo = 0, int skip_hi = 0) const {
+    // columns [skip_lo, skip_hi) are left to another writer (the policy head's action); columns at and
+    // beyond the sources' end are zero
+    __device__ __forceinline__ void commit(float *X, int KL, int Kfill, int nvalid, int skip_lo = 0, int skip_hi = 0) const {
         const int nper = Kfill >> 4;
+        const int row = threadIdx.x >> 4, p = threadIdx.x & 15;
 #pragma unroll
         for (int i = 0; i < ROWS_MAXE; ++i)
             if (i < nper) {
-                const int e = threadIdx.x + 256 * i;
-                const int row = e / Kfill, k = e - row * Kfill;
-                if (k < skip_lo || k >= skip_hi) X[lds_off(row, k, KL)] = v[i];
+                const int k = p + 16 * i;
+                if (k < skip_lo || k >= skip_hi) X[lds_off(row, k, KL)] = (k < nvalid) ? v[i] : 0.f;
             }
     }
 };
@@ -454,6 +513,7 @@ __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const fl
 
 template <int NTH, bool WIDE, int SP>
 __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ S, SlotLayout SL) {
+    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout)>();
     constexpr int NTW = 4 / SP, SW = 64 * NTW;               // tiles per wave, slice width
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
@@ -493,29 +553,33 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     SB();
     WRing<NTW, ring_depth(NTW)> r1;
     r1.init(P + L1.offW, H, n0, 16);
-    r1.fill(H >> 4);
+    if constexpr (WIDE) r1.fill(H >> 4);                     // (narrow first layers: requested inside the first GEMM)
     float bv1[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) bv1[t] = P[L1.offB + n0 + 16 * t + c];
     WRing<NTH, NTW> rh;                                      // pi: head rows x this wave's 16*NTW columns
     float w3[4 * NTW];
-#pragma unroll
-    for (int u = 0; u < 4 * NTW; ++u) w3[u] = 0.f;
-    if (is_pi) {
-        rh.init(P + L2.offW, H, 0, 16, 4 * NTW * part + NTW * wave);
-        rh.fill(NTW);
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4 * NTW; ++u) w3[u] = P[L2.offW + SW * part + p16 + 16 * u];
-    }
-    SB();
-    rows.commit(X0, KL0, K0);
+#define FWD_A_LATE_REQUESTS()                                                                          \
+    do {                                                                                               \
+        _Pragma("unroll") for (int t = 0; t < NTW; ++t) bv1[t] = P[L1.offB + n0 + 16 * t + c];         \
+        _Pragma("unroll") for (int u = 0; u < 4 * NTW; ++u) w3[u] = 0.f;                               \
+        if (is_pi) {                                                                                   \
+            rh.init(P + L2.offW, H, 0, 16, 4 * NTW * part + NTW * wave);                               \
+            rh.fill(NTW);                                                                              \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int u = 0; u < 4 * NTW; ++u) w3[u] = P[L2.offW + SW * part + p16 + 16 * u]; \
+        }                                                                                              \
+        SB();                                                                                          \
+    } while (0)
+    if constexpr (WIDE) FWD_A_LATE_REQUESTS();
+    rows.commit(X0, KL0, K0, O + (is_pi ? 0 : A));
     lds_barrier();
     STAMP(0, 1);
     {   // first layer, all 256 features (recomputed by the SP blocks of this row-block)
         f32x4 acc[4] = {};
         if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
-        else gemm_straight(r0, X0, KL0, K0 >> 4, acc);
+        else {
+            gemm_straight_pf(r0, X0, KL0, K0 >> 4, acc, r1, H >> 4);
+            FWD_A_LATE_REQUESTS();
+        }
         float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
         hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
     }
@@ -547,6 +611,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
 
 template <int NTH, bool WIDE, int SP>
 __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
@@ -571,6 +636,10 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     const bool own_s = (p4 == 0) && (part == 0), own_n = (p4 == 2) && (part == 0);
 
     STAMP(1, 0);
+#ifdef SAC_STAMPS
+    { const int kb = d.NB; asm volatile("" ::"s"(kb)); }     // first kernel argument has arrived
+    STAMP(1, 8);
+#endif
     // ---- requests, in consumption order ----
     float hm[SP], hr[SP], hbm = 0.f, hbr = 0.f, epsin = 0.f;
     const float *epp = side ? d.eps2 : d.eps1;
@@ -585,47 +654,57 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     }
     RowRegs<WIDE ? 32 : 8> rows;
     rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
-    WRing<4, WIDE ? RD : RD0> r0;
+    constexpr int D0 = WIDE ? RD : RD0, Q0 = D0 / 4;         // first-layer ring, issued in four pieces
+    const int KS0 = d.KQ >> 4;
+    WRing<4, D0> r0;
     r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
-    r0.fill(d.KQ >> 4);
     float bv0[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    r0.fill_part(KS0, 0, Q0);
     SB();
-    WRing<NTW, ring_depth(NTW)> r1;
-    r1.init(PQ + d.LQ[1].offW, H, n0, 16);
-    r1.fill(H >> 4);
-    float bv1[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) bv1[t] = PQ[d.LQ[1].offB + n0 + 16 * t + c];
-    float w3[4 * NTW];
-#pragma unroll
-    for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
-    SB();
+    STAMP(1, 9);
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
     USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
-    rows.commit(XQ, KLQ, d.KQ, O, O + A);
+    STAMP(1, 10);
+    rows.commit(XQ, KLQ, d.KQ, O, O, O + A);
     STAMP(1, 1);
-    // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
-    float lp = 0.f;
+    SB();
+    r0.fill_part(KS0, Q0, 2 * Q0);
+    SB();
+    // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same), in three
+    // pieces with the rest of the weight requests in between ----
+    float lp = 0.f, mean = 0.f, raw = 0.f, lstd = 0.f, stdv = 1.f, eps = 0.f, zz = 0.f, act = 0.f;
     if (a < A) {
-        float mean = hm[0], raw = hr[0];
+        mean = hm[0]; raw = hr[0];
 #pragma unroll
         for (int p = 1; p < SP; ++p) { mean += hm[p]; raw += hr[p]; }     // fixed order
         mean += hbm; raw += hbr;
-        const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float stdv = expf(lstd);
-        const float eps = epp ? epsin
-                              : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a),
-                                              side ? 1u : 0u);
-        const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));          // TanhNormal.rsample
-        const float act = tanhf(zz);
+        lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+        stdv = expf(lstd);
+        eps = epp ? epsin
+                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+    }
+    SB();
+    r0.fill_part(KS0, 2 * Q0, 3 * Q0);
+    SB();
+    if (a < A) {
+        zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                      // TanhNormal.rsample
+        act = tanhf(zz);
+        XQ[lds_off(row, O + a, KLQ)] = act;
+    }
+    SB();
+    r0.fill_part(KS0, 3 * Q0, D0);
+    WRing<NTW, ring_depth(NTW)> r1;
+    r1.init(PQ + d.LQ[1].offW, H, n0, 16);
+    r1.fill_part(H >> 4, 0, ring_depth(NTW) / 2);
+    SB();
+    if (a < A) {
         const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
         const float var = __fmul_rn(stdv, stdv);
         const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
         lp = nlp - logf(1.0f - act * act + TANH_EPS);
-        XQ[lds_off(row, O + a, KLQ)] = act;
         if (own_s) {
             d.mu[grow * 16 + a] = mean;
             d.ls[grow * 16 + a] = lstd;
@@ -641,6 +720,15 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     } else if (own_n) {
         d.a2[grow * 16 + a] = 0.f;
     }
+    SB();
+    r1.fill_part(H >> 4, ring_depth(NTW) / 2, ring_depth(NTW));
+    float bv1[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bv1[t] = PQ[d.LQ[1].offB + n0 + 16 * t + c];
+    float w3[4 * NTW];
+#pragma unroll
+    for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
+    SB();
     const float lsum = group16_sum(lp);
     if ((own_s || own_n) && a == 0) (side ? d.logpi2 : d.logpi)[grow] = lsum;
     if (own_s && a == 0) red[row] = lsum;
@@ -956,6 +1044,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
 // {6,7} idle: an XCD's L2 pulls one network's transposed weights); larger batches use every CU instead.
 template <int NTH, int SP>
 __global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa, int compact) {
+    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     int cls, b;
     if (compact) { cls = (blockIdx.x & 7) >> 1; b = 2 * (blockIdx.x >> 3) + (blockIdx.x & 1); }
     else { cls = blockIdx.x % 3; b = blockIdx.x / 3; }
@@ -985,6 +1074,7 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
 constexpr int NSTAT = 6;     // q1, q2, q_target, log_pi, mu, log_std
 
 __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
+    kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
     __shared__ float redb[4 * 16];
     const int B = d.B;
