@@ -217,11 +217,20 @@ def main():
                                 frac_hbm=round(gb / (prof["k_gather"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
         kern["k_mt_randint"] = dict(ms=round(prof["k_mt_randint"], 5), indices=nprof * B)
         dom = max(fl, key=lambda k: prof[k])
-        achieved = fl[dom] / (prof[dom] * 1e-3) / 1e12
+        # A launch's duration as rocprofv3's kernel trace reports it runs from dispatch to completion, i.e. it
+        # includes the ~2 us dispatch boundary (back-to-back launches: the trace's durations add up to the step).
+        # The event intervals above (minus the cost of an empty event pair) exclude it, so the boundary is added
+        # back: (timed step - sum of the intervals) / launches per step.  `achieved` uses that longer duration.
+        step_ms = elapsed_max / args.steps * 1e3
+        boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
+        dom_ms = prof[dom] + boundary_ms
+        achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic(dom) if (B == 256 and O == 42) else (None, None)
         roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
-                        traffic_source=traffic_src, flops_per_launch=fl[dom], avg_launch_ms=round(prof[dom], 5),
+                        traffic_source=traffic_src, flops_per_launch=fl[dom], avg_launch_ms=round(dom_ms, 5),
+                        exec_ms=round(prof[dom], 5), dispatch_boundary_ms=round(boundary_ms, 5),
+                        achieved_exec=round(fl[dom] / (prof[dom] * 1e-3) / 1e12, 3),
                         event_pair_ms=round(prof["event_pair"], 5),
                         whole_step=dict(gflop=round(sum(fl.values()) / 1e9, 4),
                                         tflops=round(sum(fl.values()) * value / world / 1e12, 3),

@@ -122,8 +122,13 @@ __device__ unsigned long long g_stamps[5 * 512 * 16];
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     } while (0)
+#define STAMP_CLK(kid, i)                                                                          \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < 512) g_stamps[((kid) * 512 + blockIdx.x) * 16 + (i)] = clock64(); \
+    } while (0)
 #else
 #define STAMP(kid, i) do { } while (0)
+#define STAMP_CLK(kid, i) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     const bool own_s = (p4 == 0) && (part == 0), own_n = (p4 == 2) && (part == 0);
 
     STAMP(1, 0);
+    STAMP_CLK(1, 14);
 #ifdef SAC_STAMPS
     { const int kb = d.NB; asm volatile("" ::"s"(kb)); }     // first kernel argument has arrived
     STAMP(1, 8);
@@ -778,6 +784,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     s = group16_sum(s);
     if (a == 0) d.qpart[((size_t)pass * SP + part) * B + grow] = s;
     STAMP(1, 4);
+    STAMP_CLK(1, 15);
     if (p4 >= 2) return;
     // ---- actor path: UNIT input gradient of Q_i(s, a_new) (dq = 1), partial over this block's columns ----
     // The chain dq -> dh2 -> dh1 -> da is linear in the per-row scalar dq = -sel/B, which needs min(Q1, Q2),

@@ -24,3 +24,12 @@ for sel, name in ((lambda b: (b & 7) < 4, "blocks b%8<4"), (lambda b: (b & 7) >=
     med = [np.median(ww[:, i] - t0) / 100.0 for i in range(ns)]
     print(f"kernel {kid} {name} n={len(bl)}: " + " ".join(f"s{i}={med[i]:.2f}" for i in range(ns)),
           "| max end", (ww[:, ns - 1].max() - t0) / 100.0)
+if kid == 4:
+    ww = w[:245]
+    order = [0, 3, 4, 1, 2]; names = ["start", "table", "operands", "mfma+reduce", "adam+stores"]
+    t = [np.median(ww[:, i] - t0) / 100.0 for i in order]
+    print("k_dw_adam", " ".join(f"{names[k]}={t[k]:.2f}" for k in range(5)), "| max end", (ww[:, 2].max() - t0) / 100.0)
+if kid == 1:
+    ww = w[[b for b in blocks]]
+    f = (ww[:, 15] - ww[:, 14]) / ((ww[:, 4] - ww[:, 0]) / 100.0)   # shader clocks per us
+    print("shader clock during k_fwd_b: median %.0f MHz (min %.0f, max %.0f)" % (np.median(f), f.min(), f.max()))
