@@ -56,6 +56,15 @@ int64_t sac_buffer_size(const sac_buffer_t *buf);      /* 'replay_buffer/size' *
 int64_t sac_buffer_top(const sac_buffer_t *buf);
 int64_t sac_buffer_capacity(const sac_buffer_t *buf);
 
+/* Checkpointing (SURVEY.md 8b "Snapshot contract": the reference saves no buffer -- rlkit's
+ * get_snapshot() for it is {}, /root/reference/util/rlkit_custom.py:80 -- so a resumed run starts from an
+ * empty one; here a run resumes exactly).  sac_buffer_read copies storage rows [start, start+n) to dense
+ * host arrays in the sac_buffer_add layout; restore = sac_buffer_add of the saved rows in storage order,
+ * then sac_buffer_set_cursor(top, size). */
+int sac_buffer_read(sac_buffer_t *buf, int64_t start, int64_t n, float *obs, float *act, float *rew,
+                    float *next_obs, uint8_t *term);
+int sac_buffer_set_cursor(sac_buffer_t *buf, int64_t top, int64_t size);
+
 /* The global NumPy legacy stream (np.random.seed at /root/reference/scripts/train.py:112) as the
  * replay buffer consumes it.  State layout = np.random.get_state(): key[624] + pos.  Round-tripping
  * the state keeps host NumPy consumers (env resets between training blocks) coherent. */

@@ -50,6 +50,8 @@ SYMBOLS = {
     "sac_buffer_size": (C.c_int64, [_P]),
     "sac_buffer_top": (C.c_int64, [_P]),
     "sac_buffer_capacity": (C.c_int64, [_P]),
+    "sac_buffer_read": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P, _P, _P]),
+    "sac_buffer_set_cursor": (C.c_int, [_P, C.c_int64, C.c_int64]),
     "sac_rng_seed": (C.c_int, [_P, C.c_uint32]),
     "sac_rng_get_state": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "sac_rng_set_state": (C.c_int, [_P, _P, C.c_int32]),

@@ -478,6 +478,41 @@ int sac_buffer_add_f64(sac_buffer_t *b, int64_t n, const double *obs, const doub
     return add_impl<double>(b, n, obs, act, rew, next_obs, term);
 }
 
+// Storage rows [start, start + n) -> dense host arrays (checkpointing; the reference's buffer is plain
+// NumPy arrays one can save, rlkit get_snapshot() returns {} for it -- SURVEY.md 8b "Snapshot contract").
+int sac_buffer_read(sac_buffer_t *b, int64_t start, int64_t n, float *obs, float *act, float *rew, float *next_obs,
+                    uint8_t *term) {
+    SAC_REQUIRE(b && obs && act && rew && next_obs && term, "bad arguments to sac_buffer_read");
+    SAC_REQUIRE(start >= 0 && n >= 0 && start + n <= b->capacity, "rows [%lld, %lld) outside the buffer",
+                (long long)start, (long long)(start + n));
+    if (n == 0) return 0;
+    SAC_HIP(hipSetDevice(b->device));
+    const int O = b->O, A = b->A;
+    if (sac::ensure_stage(b, sizeof(float) * (size_t)n)) return -1;
+    hipStream_t s = b->stream;
+    SAC_HIP(hipMemcpy2DAsync(obs, sizeof(float) * O, b->obs + start * b->Ost, sizeof(float) * b->Ost, sizeof(float) * O,
+                             (size_t)n, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipMemcpy2DAsync(next_obs, sizeof(float) * O, b->nobs + start * b->Ost, sizeof(float) * b->Ost,
+                             sizeof(float) * O, (size_t)n, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipMemcpy2DAsync(act, sizeof(float) * A, b->act + start * b->Ast, sizeof(float) * b->Ast, sizeof(float) * A,
+                             (size_t)n, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipMemcpyAsync(rew, b->rew + start, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipMemcpyAsync(b->h_stage, b->term + start, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipStreamSynchronize(s));
+    const float *tf = static_cast<const float *>(b->h_stage);
+    for (int64_t i = 0; i < n; ++i) term[i] = tf[i] != 0.f ? 1 : 0;
+    return 0;
+}
+
+// Restore the ring cursor after re-inserting saved rows in storage order.
+int sac_buffer_set_cursor(sac_buffer_t *b, int64_t top, int64_t size) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    SAC_REQUIRE(top >= 0 && top < b->capacity && size >= 0 && size <= b->capacity, "bad cursor (top %lld, size %lld)",
+                (long long)top, (long long)size);
+    b->top = top; b->size = size;
+    return 0;
+}
+
 int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_HIP(hipSetDevice(b->device));

@@ -16,6 +16,7 @@ from collections import OrderedDict
 
 import numpy as np
 
+from .checkpoint import load_checkpoint, save_checkpoint
 from .networks import FlattenMlp, MakeDeterministic, TanhGaussianPolicy
 from .replay_buffer import EnvReplayBuffer
 from .sac import SACTrainer
@@ -111,10 +112,24 @@ def path_information(paths, prefix, expl_len=None):
     return d
 
 
+def _rs_pack(rs):
+    st = rs.get_state()
+    return dict(key=[int(x) for x in st[1]], pos=int(st[2]), has_gauss=int(st[3]), cached=float(st[4]))
+
+
+def _rs_unpack(rs, d):
+    rs.set_state(("MT19937", np.asarray(d["key"], np.uint32), d["pos"], d["has_gauss"], d["cached"]))
+
+
 def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num_epochs=None, device=0,
-               fused_loop=True, quiet=False):
+               fused_loop=True, quiet=False, checkpoint_dir=None, resume=False):
     """variant.json -> training run.  Returns the list of progress rows (also written to
-    <log_dir>/progress.csv when log_dir is given)."""
+    <log_dir>/progress.csv when log_dir is given).
+
+    checkpoint_dir: after every epoch the full run state (networks, Adam moments, entropy coefficient, step
+    counters, replay buffer, sampling stream, host generators) is saved there (`time/saving (s)`); with
+    resume=True a run picks up after the last saved epoch and continues bit for bit -- the reference's own
+    snapshots (rlkit_custom.py:68-82) hold the networks only and cannot resume."""
     validate(variant)
     np.random.seed(seed)                                          # scripts/train.py:112 (args.seed, not variant seed)
     O, A = env_dims(variant["expl_environment_kwargs"], obs_dim, action_dim)
@@ -130,10 +145,21 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
     expl, evalc = PathCollector(expl_env, policy), PathCollector(eval_env, eval_policy)
     rows, t_start = [], time.time()
     writer, fh = None, None
-    if ak.get("min_num_steps_before_training", 0) > 0:
+    first_epoch = 0
+    host_rngs = dict(policy_noise=policy._noise, expl_env=expl_env._rs, eval_env=eval_env._rs)
+    if resume and checkpoint_dir and os.path.exists(os.path.join(checkpoint_dir, "manifest.json")):
+        extra = load_checkpoint(checkpoint_dir, trainer, buf)
+        first_epoch = int(extra["epoch"]) + 1
+        _rs_unpack(np.random, extra["np_random"])
+        for k, rs in host_rngs.items():
+            _rs_unpack(rs, extra[k])
+        expl.num_steps_total, expl.num_paths_total = extra["expl_totals"]
+        evalc.num_steps_total, evalc.num_paths_total = extra["eval_totals"]
+        trainer.end_epoch(first_epoch - 1)
+    elif ak.get("min_num_steps_before_training", 0) > 0:
         buf.add_paths(expl.collect_new_paths(ak["expl_max_path_length"], ak["min_num_steps_before_training"], False))
         expl.end_epoch(-1)
-    for epoch in range(num_epochs if num_epochs is not None else ak["num_epochs"]):
+    for epoch in range(first_epoch, num_epochs if num_epochs is not None else ak["num_epochs"]):
         t0 = time.time()
         evalc.collect_new_paths(ak["eval_max_path_length"], ak["num_eval_steps_per_epoch"], True)
         t1 = time.time()
@@ -159,22 +185,31 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
         row.update(path_information(evalc.epoch_paths, "evaluation/", ak["expl_max_path_length"]))
         trainer.end_epoch(epoch); buf.end_epoch(epoch); expl.end_epoch(epoch); evalc.end_epoch(epoch)
         t5 = time.time()
+        if checkpoint_dir:
+            extra = dict(epoch=epoch, seed=seed, np_random=_rs_pack(np.random),
+                         expl_totals=[expl.num_steps_total, expl.num_paths_total],
+                         eval_totals=[evalc.num_steps_total, evalc.num_paths_total])
+            extra.update({k: _rs_pack(rs) for k, rs in host_rngs.items()})
+            save_checkpoint(checkpoint_dir, trainer, buf, extra)
+        t6 = time.time()
         row["time/data storing (s)"] = t3 - t2
         row["time/evaluation sampling (s)"] = t1 - t0
         row["time/exploration sampling (s)"] = t2 - t1
         row["time/logging (s)"] = t5 - t4
-        row["time/saving (s)"] = 0.0
+        row["time/saving (s)"] = t6 - t5
         row["time/training (s)"] = t4 - t3
-        row["time/epoch (s)"] = t5 - t0
-        row["time/total (s)"] = t5 - t_start
+        row["time/epoch (s)"] = t6 - t0
+        row["time/total (s)"] = t6 - t_start
         row["Epoch"] = epoch
         rows.append(row)
         if log_dir is not None:
             if writer is None:
                 os.makedirs(log_dir, exist_ok=True)
-                fh = open(os.path.join(log_dir, "progress.csv"), "w", newline="")
+                appending = first_epoch > 0 and os.path.exists(os.path.join(log_dir, "progress.csv"))
+                fh = open(os.path.join(log_dir, "progress.csv"), "a" if appending else "w", newline="")
                 writer = csv.DictWriter(fh, fieldnames=list(row.keys()))
-                writer.writeheader()
+                if not appending:
+                    writer.writeheader()
             writer.writerow(row)
             fh.flush()
         if not quiet:

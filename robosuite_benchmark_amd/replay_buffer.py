@@ -108,6 +108,40 @@ class EnvReplayBuffer:
     def num_steps_can_sample(self):
         return int(self._lib.sac_buffer_size(self._h))
 
+    # ---- checkpointing (the reference saves no buffer: rlkit get_snapshot() is {}) -----------------
+    def read_rows(self, start, n):
+        """Storage rows [start, start+n) as (obs, act, rew, next_obs, term) in the add_block layout."""
+        n = int(n)
+        O, A = self._observation_dim, self._action_dim
+        o, no = np.empty((n, O), np.float32), np.empty((n, O), np.float32)
+        a, r, t = np.empty((n, A), np.float32), np.empty((n, 1), np.float32), np.empty((n, 1), np.uint8)
+        _lib.check(self._lib.sac_buffer_read(self._h, int(start), n, *(map(_lib.ptr, (o, a, r, no, t)))),
+                   "sac_buffer_read")
+        return o, a, r, no, t
+
+    def state_dict(self):
+        """Everything a bit-exact resume needs: the valid rows in storage order, ring cursor, generator state."""
+        size, top = int(self._lib.sac_buffer_size(self._h)), int(self._lib.sac_buffer_top(self._h))
+        o, a, r, no, t = self.read_rows(0, size)                  # the ring fills from row 0
+        key, pos = self.rng_state()
+        return dict(capacity=self._max_replay_buffer_size, obs_dim=self._observation_dim, action_dim=self._action_dim,
+                    top=top, size=size, observations=o, actions=a, rewards=r, next_observations=no, terminals=t,
+                    rng_key=key, rng_pos=pos)
+
+    def load_state_dict(self, st, chunk=1 << 18):
+        if (int(st["capacity"]), int(st["obs_dim"]), int(st["action_dim"])) != (
+                self._max_replay_buffer_size, self._observation_dim, self._action_dim):
+            raise ValueError("checkpointed replay buffer has another shape")
+        size = int(st["size"])
+        _lib.check(self._lib.sac_buffer_set_cursor(self._h, 0, 0), "sac_buffer_set_cursor")
+        for i in range(0, size, chunk):
+            j = min(size, i + chunk)
+            self.add_block(*(np.asarray(st[k][i:j]) for k in ("observations", "actions", "rewards",
+                                                               "next_observations", "terminals")))
+        _lib.check(self._lib.sac_buffer_set_cursor(self._h, int(st["top"]), size), "sac_buffer_set_cursor")
+        key = np.ascontiguousarray(st["rng_key"], dtype=np.uint32)
+        _lib.check(self._lib.sac_rng_set_state(self._h, _lib.ptr(key), int(st["rng_pos"])), "sac_rng_set_state")
+
     def random_batch(self, batch_size, return_indices=False):
         B, O, A = int(batch_size), self._observation_dim, self._action_dim
         obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)

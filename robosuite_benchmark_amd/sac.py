@@ -100,6 +100,7 @@ class SACTrainer:
                                                    m.size), "sac_set_opt_state")
         sc = np.ascontiguousarray(st["scalars"], np.float64)
         _lib.check(self._lib.sac_set_scalars(self._h, _lib.ptr(sc)), "sac_set_scalars")
+        self._host_policy_stale = True           # the acting copy on the host is refreshed at its next use
 
     state_dict, load_state_dict = _export_state, _import_state
 

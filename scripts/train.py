@@ -19,11 +19,18 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--env", type=str, default="Lift")
     ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--resume", type=str, default=None,
+                    help="an existing run directory (…_0000--s-0): continue it from its checkpoint/ after the last saved epoch")
+    ap.add_argument("--no_checkpoint", action="store_true", help="do not save <run_dir>/checkpoint after every epoch")
     args = ap.parse_args()
     variant = load_variant(args.variant) if args.variant else default_variant(env=args.env, seed=args.seed,
                                                                               batch_size=args.batch_size)
     run_dir = None
-    if args.log_dir:
+    if args.resume:
+        import json
+        run_dir = args.resume
+        variant = json.load(open(os.path.join(run_dir, "variant.json")))
+    elif args.log_dir:
         # the reference's run-directory layout (rlkit setup_logger, observed under runs/):
         #   <log_dir>/<Prefix-with-dashes>/<prefix>_<timestamp>_0000--s-0/{variant.json, progress.csv}
         import datetime
@@ -34,4 +41,6 @@ if __name__ == "__main__":
         run_dir = os.path.join(args.log_dir, prefix.replace("_", "-"), f"{prefix}_{stamp}_0000--s-0")
         os.makedirs(run_dir, exist_ok=True)
         json.dump(variant, open(os.path.join(run_dir, "variant.json"), "w"), indent=2, sort_keys=True)
-    experiment(variant, log_dir=run_dir, seed=args.seed, num_epochs=args.epochs)
+    ckpt = os.path.join(run_dir, "checkpoint") if (run_dir and not args.no_checkpoint) else None
+    experiment(variant, log_dir=run_dir, seed=args.seed, num_epochs=args.epochs, checkpoint_dir=ckpt,
+               resume=bool(args.resume))
