@@ -143,6 +143,25 @@ def cpu_baseline(O, A, B, seconds_budget=24.0):
                 host_cpus=os.cpu_count())
 
 
+def concurrent_replicas(task, O, A, B, n_replicas, steps, device):
+    """Extra data point, never `value`: R independent runs (own buffer, nets, streams) driven from R host threads
+    on ONE GPU -- the reference's real workload is 5 seeds x 29 configurations of independent jobs
+    (/root/reference/launch_jobs.sh:15-24), and a single batch-256 run leaves most of the chip idle."""
+    import threading
+    reps = [build_replica(task, O, A, B, 100_000, 100 + i, device) for i in range(n_replicas)]
+    for tr, buf in reps:
+        tr.train_loop(buf, 100, batch_size=B)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=tr.train_loop, args=(buf, steps), kwargs=dict(batch_size=B)) for tr, buf in reps]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    return dict(replicas=n_replicas, steps_each=steps, value=round(n_replicas * steps / el, 2), unit="grad-steps/s",
+                note="aggregate of independent runs sharing one GPU (100000-slot buffers); not the headline metric")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +177,8 @@ def main():
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
     ap.add_argument("--profile-steps", type=int, default=500)
+    ap.add_argument("--replicas-per-gpu", type=int, default=0,
+                    help="N=1 only: also time R concurrent independent runs on the GPU (reported beside, never as, value)")
     args = ap.parse_args()
 
     rank, local_rank, world = parallel.rank_info()
@@ -263,6 +284,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, A, B)
         elif world == 1:
             out["cpu_baseline"] = None
+        if world == 1 and args.replicas_per_gpu > 1:
+            out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, local_rank)
     barrier()
     if dist is not None:
         dist.destroy_process_group()

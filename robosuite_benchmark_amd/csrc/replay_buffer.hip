@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
             if (write_saT && has_s) {
                 float4 v;
                 v.x = lds[ms[0]]; v.y = lds[ms[1]]; v.z = lds[ms[2]]; v.w = lds[ms[3]];
-                *reinterpret_cast<float4 *>(S + L.off_saT + (int64_t)(tid >> 2) * B + row0 + 4 * (tid & 3)) = v;
+                const int f = tid >> 2, frow = (f < O) ? f : L.KA + (f - O);
+                *reinterpret_cast<float4 *>(S + L.off_saT + (int64_t)frow * B + row0 + 4 * (tid & 3)) = v;
             }
             lds_barrier();                         // tile free for the next block
             return;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                     const int r = 4 * q + j;
                     pv[j] = (f < O) ? t_obs[r * Ost + f] : t_act[r * Ast + (f - O)];
                 }
-                *reinterpret_cast<float4 *>(T + (int64_t)f * B + row0 + 4 * q) = v;
+                *reinterpret_cast<float4 *>(T + (int64_t)((f < O) ? f : L.KA + (f - O)) * B + row0 + 4 * q) = v;
             }
         }
         lds_barrier();                             // tile free for the next block
@@ -304,7 +305,7 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
         b->d_slots = nullptr;
         b->slots_cap = 0;
         SAC_HIP(hipMalloc(&b->d_slots, sizeof(float) * need));
-        // padding rows of saT (features >= O+A) are contracted by the weight-gradient kernel: keep them 0
+        // padding rows of saT (between and after obs / act) are contracted by the weight-gradient kernel: keep them 0
         SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
         b->slots_cap = need;
     } else if (b->slot.B != B) {

@@ -38,10 +38,13 @@ static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m 
 
 // Layout of one minibatch slot in HBM (floats).  Written by the gather kernel, read by the step
 // kernels.  Row-major part == what random_batch returns; saT is the feature-major copy
-// [KQ][B] of cat(obs, act) that the weight-gradient kernel contracts over the batch.
+// [KQ][B] of the Q-net input that the weight-gradient kernel contracts over the batch.  The Q-net input is laid
+// out [obs | 0-pad to KA | act | 0-pad to KQ] with KA = round_up(O, 16): the action sits in a k-chunk (16 columns)
+// of its own, so a first-layer GEMM can be split into its observation part and its action part.
 struct SlotLayout {
     int B, O, A;
-    int KQ;                       // round_up(O + A, 16)
+    int KA;                       // first action row of saT / action column of the Q-net input: round_up(O, 16)
+    int KQ;                       // KA + 16
     int KQ64;                     // rows allocated for saT: round_up(KQ, 64) (64-wide k strips)
     int64_t off_obs, off_act, off_rew, off_term, off_nobs, off_saT;
     int64_t slot_floats;          // multiple of 64 floats (256 B)
@@ -50,7 +53,8 @@ struct SlotLayout {
 static inline SlotLayout make_slot_layout(int B, int O, int A) {
     SlotLayout L;
     L.B = B; L.O = O; L.A = A;
-    L.KQ = round_up(O + A, 16);
+    L.KA = round_up(O, 16);
+    L.KQ = L.KA + 16;
     L.KQ64 = round_up(L.KQ, 64);
     int64_t off = 0;
     L.off_obs = off;  off += round_up64((int64_t)B * O, 64);

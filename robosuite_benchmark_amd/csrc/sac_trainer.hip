@@ -73,7 +73,7 @@ struct Net {
 
 // everything the step kernels need, passed by value
 struct Dev {
-    int B, O, A, KP, KQ, NH, NB;   // KP = pad16(O), KQ = pad16(O+A), NH = pad16(2A), NB = B/16
+    int B, O, A, KP, KQ, NH, NB;   // KP = pad16(O), KQ = KP + 16 (Q input: [obs | pad | act | pad]), NH = pad16(2A), NB = B/16
     float discount, reward_scale, tau, target_entropy, alpha_lr;
     int period, auto_alpha;
     unsigned long long noise_seed;
@@ -426,32 +426,34 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
 template <int ROWS_MAXE>                      // Kfill <= 16 * ROWS_MAXE
 struct RowRegs {
     float v[ROWS_MAXE];
+    // columns [0, n0) from s0, [c1, c1 + n1) from s1, zero elsewhere
     __device__ __forceinline__ void issue(int Kfill, const float *__restrict__ s0, int n0, int ld0,
-                                          const float *__restrict__ s1, int n1, int ld1) {
+                                          const float *__restrict__ s1, int n1, int ld1, int c1) {
         const int nper = Kfill >> 4;          // RB * Kfill / 256
         const int row = threadIdx.x >> 4, p = threadIdx.x & 15;
         const float *r0 = s0 + row * ld0;
-        const float *r1 = (n1 > 0 ? s1 + row * ld1 : r0) - (n1 > 0 ? n0 : 0);
+        const float *r1 = (n1 > 0 ? s1 + row * ld1 : r0) - (n1 > 0 ? c1 : 0);
 #pragma unroll
         for (int i = 0; i < ROWS_MAXE; ++i) {
             v[i] = 0.f;
             if (i < nper) {
                 const int k = p + 16 * i;
-                const float *src = (k < n0) ? r0 + k : ((k < n0 + n1) ? r1 + k : r0);
+                const float *src = (k < n0) ? r0 + k : ((k >= c1 && k < c1 + n1) ? r1 + k : r0);
                 v[i] = *src;
             }
         }
     }
-    // columns [skip_lo, skip_hi) are left to another writer (the policy head's action); columns at and
-    // beyond the sources' end are zero
-    __device__ __forceinline__ void commit(float *X, int KL, int Kfill, int nvalid, int skip_lo = 0, int skip_hi = 0) const {
+    // columns [skip_lo, skip_hi) are left to another writer (the policy head's action)
+    __device__ __forceinline__ void commit(float *X, int KL, int Kfill, int n0, int c1, int n1, int skip_lo = 0,
+                                           int skip_hi = 0) const {
         const int nper = Kfill >> 4;
         const int row = threadIdx.x >> 4, p = threadIdx.x & 15;
 #pragma unroll
         for (int i = 0; i < ROWS_MAXE; ++i)
             if (i < nper) {
                 const int k = p + 16 * i;
-                if (k < skip_lo || k >= skip_hi) X[lds_off(row, k, KL)] = (k < nvalid) ? v[i] : 0.f;
+                const bool valid = (k < n0) || (k >= c1 && k < c1 + n1);
+                if (k < skip_lo || k >= skip_hi) X[lds_off(row, k, KL)] = valid ? v[i] : 0.f;
             }
     }
 };
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     STAMP(0, 0);
     // ---- requests, in consumption order ----
     RowRegs<WIDE ? 32 : 8> rows;
-    rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, is_pi ? 0 : A, A);
+    rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, is_pi ? 0 : A, A, d.KP);
     WRing<4, WIDE ? RD : RD0> r0;
     r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
     r0.fill(K0 >> 4);
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         SB();                                                                                          \
     } while (0)
     if constexpr (WIDE) FWD_A_LATE_REQUESTS();
-    rows.commit(X0, KL0, K0, O + (is_pi ? 0 : A));
+    rows.commit(X0, KL0, K0, O, d.KP, is_pi ? 0 : A);
     lds_barrier();
     STAMP(0, 1);
     {   // first layer, all 256 features (recomputed by the SP blocks of this row-block)
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         if (epp) epsin = epp[grow * A + am];
     }
     RowRegs<WIDE ? 32 : 8> rows;
-    rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0);
+    rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
     constexpr int D0 = WIDE ? RD : RD0, Q0 = D0 / 4;         // first-layer ring, issued in four pieces
     const int KS0 = d.KQ >> 4;
     WRing<4, D0> r0;
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
     USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
     STAMP(1, 10);
-    rows.commit(XQ, KLQ, d.KQ, O, O, O + A);
+    rows.commit(XQ, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + A);
     STAMP(1, 1);
     SB();
     r0.fill_part(KS0, Q0, 2 * Q0);
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     if (a < A) {
         zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                      // TanhNormal.rsample
         act = tanhf(zz);
-        XQ[lds_off(row, O + a, KLQ)] = act;
+        XQ[lds_off(row, d.KP + a, KLQ)] = act;
     }
     SB();
     r0.fill_part(KS0, 3 * Q0, D0);
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
             rw.init(PT + d.LQ[1].offWt, H, 64 * wave, 16, 4 * NTW * part);
             rw.fill(4 * NTW);
         }
-        ra.init(PT + d.LQ[0].offWt + (size_t)O * H, H, 0, 16, 4 * wave);
+        ra.init(PT + d.LQ[0].offWt + (size_t)d.KP * H, H, 0, 16, 4 * wave);
         ra.fill(4);
         SB();
     }
@@ -1417,8 +1419,9 @@ void for_each_param(const sac_trainer *t, int netid, F &&fn) {
     for (int l = 0; l < f.nl; ++l) {
         const int dl = (l < 2) ? l : 2;                       // policy heads share device layer 2
         const int nshift = (netid == SAC_NET_POLICY && l == 3) ? t->A : 0;
+        const bool qin = (netid != SAC_NET_POLICY) && l == 0;   // Q first layer: action columns start at KP
         for (int n = 0; n < f.N[l]; ++n)
-            for (int k = 0; k < f.K[l]; ++k) fn(fi++, dl, n + nshift, k, false);
+            for (int k = 0; k < f.K[l]; ++k) fn(fi++, dl, n + nshift, (qin && k >= t->O) ? t->KP + (k - t->O) : k, false);
         for (int n = 0; n < f.N[l]; ++n) fn(fi++, dl, n + nshift, 0, true);
     }
 }
@@ -1487,7 +1490,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     sac_trainer *t = new sac_trainer();
     t->cfg = *cfg; t->device = cfg->device;
     t->B = cfg->batch; t->O = cfg->obs_dim; t->A = cfg->act_dim;
-    t->KP = round_up(t->O, 16); t->KQ = round_up(t->O + t->A, 16); t->NH = round_up(2 * t->A, 16);
+    t->KP = round_up(t->O, 16); t->KQ = t->KP + 16; t->NH = round_up(2 * t->A, 16);
     t->NB = t->B / 16;
     // column split: small batches spread every 256-wide layer over 4 workgroups per row-block; once the
     // row-blocks alone fill the 256 CUs (B >= 512) fewer, fatter workgroups win.  SP*NB stays even (XCD map).
@@ -1502,7 +1505,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     Arena arena;
     g_arena = &arena;
     const int shp[3][2] = {{H, t->O}, {H, H}, {2 * t->A, H}};
-    const int shq[3][2] = {{H, t->O + t->A}, {H, H}, {1, H}};
+    const int shq[3][2] = {{H, t->KQ}, {H, H}, {1, H}};     // device K of the Q first layer: padded [obs | act] layout
     for (int i = 0; i < 5; ++i) {
         Net &n = t->net[i];
         build_layers(n, i == 0 ? shp : shq, 3);
@@ -1751,7 +1754,7 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     memset(sT, 0, sizeof(float) * (size_t)L.KQ64 * B);
     for (int b = 0; b < B; ++b) {
         for (int k = 0; k < O; ++k) sT[(size_t)k * B + b] = obs[(size_t)b * O + k];
-        for (int k = 0; k < A; ++k) sT[(size_t)(O + k) * B + b] = act[(size_t)b * A + k];
+        for (int k = 0; k < A; ++k) sT[(size_t)(L.KA + k) * B + b] = act[(size_t)b * A + k];
     }
     float *E = t->ext_slot;
     SAC_HIP(hipMemcpyAsync(E + L.off_obs, so, sizeof(float) * B * O, hipMemcpyHostToDevice, s));
