@@ -86,6 +86,7 @@ struct Dev {
     float *PH1T, *PH2T, *mu, *ls, *lsok, *z, *anew, *epsv, *logpi, *a2, *logpi2, *part_logpi;
     // Q forward: passes 0..3 keep h1/h2 feature-major; q values for all 6 passes
     float *QH1T, *QH2T, *q;
+    float *QU;                     // Q1,Q2(s,a) first-layer pre-activations, feature-major [2][256][B]
     // backward
     float *y, *dq16T, *dQH2T, *dQH1T, *dheadT, *dPH2T, *dPH1T;
     // partial sums of the column-split layers (added by the consuming launch, fixed order)
@@ -220,10 +221,10 @@ struct WRing {
     }
     // chunks [u0, u1) of the first min(D, KS): the prologues issue a ring in pieces between independent
     // work -- a wave whose loads outrun the CU's fill path (~20 B/clk) just stalls at issue
-    __device__ __forceinline__ void fill_part(int KS, int u0, int u1) {
+    __device__ __forceinline__ void fill_part(int KS, int u0, int u1, int lo = 0) {
 #pragma unroll
         for (int u = 0; u < D; ++u)
-            if (u >= u0 && u < u1 && u < KS) {
+            if (u >= u0 && u < u1 && u < KS && u >= lo) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 16 * u);
             }
@@ -326,13 +327,14 @@ __device__ __forceinline__ void gemm_lds_rows(const float *WL, int col0, const f
 // only when no loop back-edge separates a load from its use (with a runtime trip count it falls
 // back to vmcnt(0), which would drain the NEXT layer's 64 KB prefetch before this GEMM starts).
 template <int NT, int D>
-__device__ __forceinline__ void gemm_straight(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT]) {
+__device__ __forceinline__ void gemm_straight(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
+                                              int lo = 0) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
 #pragma unroll
     for (int u = 0; u < D; ++u) {
-        if (u < KS) {
+        if (u >= lo && u < KS) {
             const f32x4 a = ld4(xrow + 4 * ((4 * u + g) ^ r));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -458,24 +460,30 @@ struct RowRegs {
     }
 };
 
-// epilogue of a hidden layer: bias + relu from the accumulators into the next LDS row-block, and
-// (optionally) the feature-major copy [n][B] for the weight-gradient kernel.
+// epilogue of a hidden layer: bias + relu from the accumulators into the next LDS row-block; the values stay in
+// `keep` for store_features().  The feature-major global copy [n][B] (for the weight-gradient kernel) is NOT stored
+// here: vmcnt retires loads and stores in issue order, so a store issued in front of the next GEMM's weight
+// requests would put its ~1.5 us write latency into every later s_waitcnt -- it is issued once the kernel has
+// requested all its loads.
 template <int NT>
 __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_base, int n_stride,
-                                                const float (&bv)[NT], float *Xn, int KL, float *outT, int B,
-                                                int row0) {
+                                                const float (&bv)[NT], float *Xn, int KL, f32x4 (&keep)[NT]) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = n_base + t * n_stride + c;
-        f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = fmaxf(acc[t][i] + bv[t], 0.f);
-            Xn[lds_off(4 * g + i, n, KL)] = v[i];
+            keep[t][i] = fmaxf(acc[t][i] + bv[t], 0.f);
+            Xn[lds_off(4 * g + i, n, KL)] = keep[t][i];
         }
-        if (outT) st4(outT + (size_t)n * B + row0 + 4 * g, v);
     }
+}
+template <int NT>
+__device__ __forceinline__ void store_features(const f32x4 (&v)[NT], int n_base, int n_stride, float *outT, int B, int row0) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) st4(outT + (size_t)(n_base + t * n_stride + c) * B + row0 + 4 * g, v[t]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -580,6 +588,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     rows.commit(X0, KL0, K0, O, d.KP, is_pi ? 0 : A);
     lds_barrier();
     STAMP(0, 1);
+    f32x4 keep1[4], zkeep[4];
     {   // first layer, all 256 features (recomputed by the SP blocks of this row-block)
         f32x4 acc[4] = {};
         if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
@@ -587,14 +596,26 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
             gemm_straight_pf(r0, X0, KL0, K0 >> 4, acc, r1, H >> 4);
             FWD_A_LATE_REQUESTS();
         }
-        float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
+        // Q blocks keep this quarter's PRE-activation z = W1 [s, a] + b for launch B: the first layer is linear in
+        // the action, so Q_i(s, a_new) only needs z + W1[:, action chunk] (a_new - a) there instead of streaming
+        // the whole first layer again
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) zkeep[t][i] = acc[t][i] + bv0[t];
+        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, keep1);
     }
     lds_barrier();
     STAMP(0, 2);
     {   // this block's columns of the 256x256 layer
         f32x4 acc[NTW] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
+        // every load of the kernel has been requested: now the feature-major copies of this block's quarter
+        if (wave / NTW == part) {
+            float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
+            if (h1T) store_features<4>(keep1, 64 * wave, 16, h1T, B, row0);
+            if (!is_pi && !WIDE) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
+        }
         float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
@@ -660,26 +681,47 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         hbr = d.P[0][d.LP[2].offB + A + am];
         if (epp) epsin = epp[grow * A + am];
     }
-    RowRegs<WIDE ? 32 : 8> rows;
-    rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
+    // Q1/Q2(s, a_new) blocks (narrow first layers): launch A left the first-layer pre-activations z of Q_i(s, a) in
+    // QU and the layer is linear in the action, so z + W1[:, action chunk] (a_new - a) needs only the action chunk
+    // of the weights and of the input; target-net blocks do the whole layer.
+    const bool act_only = !WIDE && (p4 < 2);
     constexpr int D0 = WIDE ? RD : RD0, Q0 = D0 / 4;         // first-layer ring, issued in four pieces
     const int KS0 = d.KQ >> 4;
+    const int lo0 = act_only ? KS0 - 1 : 0;                  // first chunk of the first layer this block computes
+    RowRegs<WIDE ? 32 : 8> rows;
+    f32x4 acc0[4] = {}, keep1[4];                            // first-layer accumulators (start: 0, or launch A's z)
+    if (!act_only) rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
     WRing<4, D0> r0;
     r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
     float bv0[4];
+    float abat = 0.f;                                        // the batch action a (act_only blocks)
+    if (act_only) {
+        abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
+        const float *qu = d.QU + ((size_t)p4 * H + 64 * wave + c) * B + row0 + 4 * (lane >> 4);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
-    r0.fill_part(KS0, 0, Q0);
+        for (int t = 0; t < 4; ++t) { acc0[t] = ld4(qu + (size_t)16 * t * B); bv0[t] = 0.f; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    }
+    // the 256x256 slice's ring: target-net blocks request it behind the first layer's weights (around the last piece
+    // of the head math), act_only blocks -- which stream no first layer -- in four pieces from the start
+    constexpr int RD1 = ring_depth(NTW), QR = RD1 / 4;
+    WRing<NTW, RD1> r1;
+    r1.init(PQ + d.LQ[1].offW, H, n0, 16);
+    r0.fill_part(KS0, 0, Q0, lo0);
+    r1.fill_part(H >> 4, 0, act_only ? QR : 0);
     SB();
     STAMP(1, 9);
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(hm[p]); USE_FROM_HERE(hr[p]); }
     USE_FROM_HERE(hbm); USE_FROM_HERE(hbr); USE_FROM_HERE(epsin);
     STAMP(1, 10);
-    rows.commit(XQ, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + A);
+    if (!act_only) rows.commit(XQ, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + 16);     // the head writes the action chunk
     STAMP(1, 1);
     SB();
-    r0.fill_part(KS0, Q0, 2 * Q0);
+    r0.fill_part(KS0, Q0, 2 * Q0, lo0);
+    r1.fill_part(H >> 4, QR, act_only ? 2 * QR : 0);
     SB();
     // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same), in three
     // pieces with the rest of the weight requests in between ----
@@ -695,18 +737,18 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
                   : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
     }
     SB();
-    r0.fill_part(KS0, 2 * Q0, 3 * Q0);
+    r0.fill_part(KS0, 2 * Q0, 3 * Q0, lo0);
+    r1.fill_part(H >> 4, 2 * QR, act_only ? 3 * QR : 0);
     SB();
     if (a < A) {
         zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                      // TanhNormal.rsample
         act = tanhf(zz);
-        XQ[lds_off(row, d.KP + a, KLQ)] = act;
     }
+    // the whole action chunk (0 beyond A); act_only blocks contract the difference to the batch action
+    XQ[lds_off(row, d.KP + a, KLQ)] = (a < A) ? (act_only ? act - abat : act) : 0.f;
     SB();
-    r0.fill_part(KS0, 3 * Q0, D0);
-    WRing<NTW, ring_depth(NTW)> r1;
-    r1.init(PQ + d.LQ[1].offW, H, n0, 16);
-    r1.fill_part(H >> 4, 0, ring_depth(NTW) / 2);
+    r0.fill_part(KS0, 3 * Q0, D0, lo0);
+    r1.fill_part(H >> 4, act_only ? 3 * QR : 0, act_only ? RD1 : RD1 / 2);
     SB();
     if (a < A) {
         const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
@@ -729,7 +771,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         d.a2[grow * 16 + a] = 0.f;
     }
     SB();
-    r1.fill_part(H >> 4, ring_depth(NTW) / 2, ring_depth(NTW));
+    r1.fill_part(H >> 4, RD1 / 2, act_only ? 0 : RD1);
     float bv1[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) bv1[t] = PQ[d.LQ[1].offB + n0 + 16 * t + c];
@@ -749,11 +791,9 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     STAMP(1, 2);
     // ---- Q / target-Q net on cat(obs, action) ----
     {
-        f32x4 acc[4] = {};
-        if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, d.KQ >> 4, acc);
-        else gemm_straight(r0, XQ, KLQ, d.KQ >> 4, acc);
-        float *h1T = (p4 < 2) ? d.QH1T + (size_t)pass * H * B : nullptr;
-        hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, (wave / NTW == part) ? h1T : nullptr, B, row0);
+        if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, KS0, acc0);
+        else gemm_straight(r0, XQ, KLQ, KS0, acc0, lo0);
+        hidden_epilogue<4>(acc0, 64 * wave, 16, bv0, X1, H, keep1);
     }
     // Q1/Q2(s,a_new) blocks go on to the actor's input gradient (below): request its weights now (the first
     // layer's ring registers are free), so they arrive under the 256x256 slice.
@@ -776,6 +816,8 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         f32x4 acc[NTW] = {};
         if (STAGE && p4 < 2) gemm_ring<true>(r1, X1, H, H >> 4, acc, 0, WL + 16 * NTW * wave);
         else gemm_ring(r1, X1, H, H >> 4, acc);
+        if (p4 < 2 && (wave / NTW == part))       // (all loads of the forward part have been requested)
+            store_features<4>(keep1, 64 * wave, 16, d.QH1T + (size_t)pass * H * B, B, row0);
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
@@ -1521,7 +1563,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
         {&d.PH1T, (long long)H * B}, {&d.PH2T, (long long)H * B},
         {&d.mu, 16LL * B}, {&d.ls, 16LL * B}, {&d.lsok, 16LL * B}, {&d.z, 16LL * B}, {&d.anew, 16LL * B},
         {&d.epsv, 16LL * B}, {&d.logpi, B}, {&d.a2, 16LL * B}, {&d.logpi2, B}, {&d.part_logpi, round_up(t->NB, 64)},
-        {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B},
+        {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B}, {&d.QU, 2LL * H * B},
         {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
         {&d.headpart, 2LL * t->NB * 4 * RB * 32}, {&d.qpart, 6LL * 4 * B}, {&d.dapart, 2LL * 4 * B * 16},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
