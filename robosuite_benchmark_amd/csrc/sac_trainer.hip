@@ -755,20 +755,6 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         const float var = __fmul_rn(stdv, stdv);
         const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
         lp = nlp - logf(1.0f - act * act + TANH_EPS);
-        if (own_s) {
-            d.mu[grow * 16 + a] = mean;
-            d.ls[grow * 16 + a] = lstd;
-            d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
-            d.z[grow * 16 + a] = zz;
-            d.anew[grow * 16 + a] = act;
-            d.epsv[grow * 16 + a] = eps;
-        } else if (own_n) {
-            d.a2[grow * 16 + a] = act;
-        }
-    } else if (own_s) {
-        d.anew[grow * 16 + a] = 0.f;
-    } else if (own_n) {
-        d.a2[grow * 16 + a] = 0.f;
     }
     SB();
     r1.fill_part(H >> 4, RD1 / 2, act_only ? 0 : RD1);
@@ -780,14 +766,14 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
     SB();
     const float lsum = group16_sum(lp);
-    if ((own_s || own_n) && a == 0) (side ? d.logpi2 : d.logpi)[grow] = lsum;
     if (own_s && a == 0) red[row] = lsum;
     lds_barrier();
+    float lsum_blk = 0.f;
     if (own_s && threadIdx.x == 0) {          // this row-block's sum(log_pi), fixed order
-        float s = 0.f;
-        for (int i = 0; i < RB; ++i) s += red[i];
-        d.part_logpi[rb] = s;
+        for (int i = 0; i < RB; ++i) lsum_blk += red[i];
     }
+    // (the head's global results are stored behind the slice GEMM, once every load has been requested: vmcnt
+    //  retires in issue order, a store in front of the weight requests would sit in all their waits)
     STAMP(1, 2);
     // ---- Q / target-Q net on cat(obs, action) ----
     {
@@ -818,6 +804,21 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         else gemm_ring(r1, X1, H, H >> 4, acc);
         if (p4 < 2 && (wave / NTW == part))       // (all loads of the forward part have been requested)
             store_features<4>(keep1, 64 * wave, 16, d.QH1T + (size_t)pass * H * B, B, row0);
+        if (own_s) {
+            if (a < A) {
+                d.mu[grow * 16 + a] = mean;
+                d.ls[grow * 16 + a] = lstd;
+                d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
+                d.z[grow * 16 + a] = zz;
+                d.epsv[grow * 16 + a] = eps;
+            }
+            d.anew[grow * 16 + a] = act;                      // (0 beyond A)
+            if (a == 0) d.logpi[grow] = lsum;
+            if (threadIdx.x == 0) d.part_logpi[rb] = lsum_blk;
+        } else if (own_n) {
+            d.a2[grow * 16 + a] = act;
+            if (a == 0) d.logpi2[grow] = lsum;
+        }
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
     }
@@ -924,37 +925,28 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
+    float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
     if (threadIdx.x < RB) {
-        const int r = row0 + threadIdx.x;
-        float va = qa[0], vb = qb[0], vq = qq[0];
+        va = qa[0]; vb = qb[0]; vq = qq[0];
 #pragma unroll
         for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; vq += qq[p]; }      // fixed order
         va += b3a;                                                       // T1(s',a')
         vb += b3b;                                                       // T2(s',a')
         vq += b3q;                                                       // Q_i(s,a)
         const float tq = fminf(va, vb) - alpha * in_c;
-        const float yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
-        const float dq = 2.0f * (vq - yv) * invB;
-        if (part == 0) {
-            d.q[(size_t)qi * B + r] = vq;
-            d.dq16T[(size_t)qi * 16 * B + r] = dq;                      // row 0 of the padded [16][B]
-            if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
-        }
+        yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
+        dq = 2.0f * (vq - yv) * invB;
         s_dq[threadIdx.x] = dq;
     }
     lds_barrier();
     // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner block
-    {
-        float *outT = ((k / SW) == part) ? d.dQH2T + (size_t)qi * H * B : nullptr;
+    f32x4 gv2[4];
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            f32x4 gv;
+    for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                gv[i] = (h2v[qd][i] > 0.f) ? s_dq[4 * qd + i] * wk : 0.f;
-                X2[lds_off(4 * qd + i, k, H)] = gv[i];
-            }
-            if (outT) st4(outT + (size_t)k * B + row0 + 4 * qd, gv);
+        for (int i = 0; i < 4; ++i) {
+            gv2[qd][i] = (h2v[qd][i] > 0.f) ? s_dq[4 * qd + i] * wk : 0.f;
+            X2[lds_off(4 * qd + i, k, H)] = gv2[qd][i];
         }
     }
     lds_barrier();
@@ -962,6 +954,17 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     {
         f32x4 acc[NTW] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
+        // global results only now that every load has been requested (vmcnt retires loads and stores in issue order)
+        if (threadIdx.x < RB && part == 0) {
+            const int r = row0 + threadIdx.x;
+            d.q[(size_t)qi * B + r] = vq;
+            d.dq16T[(size_t)qi * 16 * B + r] = dq;                      // row 0 of the padded [16][B]
+            if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
+        }
+        if ((k / SW) == part) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) st4(d.dQH2T + (size_t)qi * H * B + (size_t)k * B + row0 + 4 * qd, gv2[qd]);
+        }
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             f32x4 gv;
@@ -1034,6 +1037,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     for (int p = 0; p < 2 * SP; ++p) USE_FROM_HERE(dap[p]);
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); }
+    float qnew1 = 0.f, qnew2 = 0.f, dz = 0.f, dls = 0.f;
     {
         float va = qa[0], vb = qb[0];
 #pragma unroll
@@ -1042,44 +1046,48 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
         // torch.min backward: the smaller one takes the gradient, a tie splits it
         const float sel1 = (va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f);
         const float dq1 = -invB * sel1, dq2 = -invB * (1.0f - sel1);
-        if (part == 0 && a == 0) { d.q[2 * (size_t)B + row0 + row] = va; d.q[3 * (size_t)B + row0 + row] = vb; }
+        qnew1 = va; qnew2 = vb;
         if (a < A) {
             float da1 = dap[0], da2 = dap[SP];
 #pragma unroll
             for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
             const float da = da1 * dq1 + da2 * dq2;
             const float om = 1.0f - act * act;
-            const float dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+            dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
             const float stdv = expf(lsv);
-            const float dls = (dz * stdv * epv - alpha * invB) * okv;
+            dls = (dz * stdv * epv - alpha * invB) * okv;
             XH[lds_off(row, a, 64)] = dz;
             XH[lds_off(row, A + a, 64)] = dls;
-            if (part == 0) {
-                d.dheadT[(size_t)a * B + row0 + row] = dz;
-                d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
-            }
         }
     }
     lds_barrier();
+    f32x4 gk2[4];
     {
         f32x4 acc[4] = {};
         gemm_ring(rh, XH, 64, NTH, acc);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = 64 * wave + 16 * t + c;
-            f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                gv[i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
-                X2[lds_off(4 * g + i, n, H)] = gv[i];
+                gk2[t][i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
+                X2[lds_off(4 * g + i, n, H)] = gk2[t][i];
             }
-            if (wave / NTW == part) st4(d.dPH2T + (size_t)n * B + row0 + 4 * g, gv);
         }
     }
     lds_barrier();
     {
         f32x4 acc[NTW] = {};
         gemm_ring(r1, X2, H, H >> 4, acc);
+        // global results only now that every load has been requested (vmcnt retires loads and stores in issue order)
+        if (part == 0) {
+            if (a == 0) { d.q[2 * (size_t)B + row0 + row] = qnew1; d.q[3 * (size_t)B + row0 + row] = qnew2; }
+            if (a < A) {
+                d.dheadT[(size_t)a * B + row0 + row] = dz;
+                d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+            }
+        }
+        if (wave / NTW == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             f32x4 gv;
