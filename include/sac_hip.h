@@ -82,6 +82,17 @@ int sac_sample_indices(sac_buffer_t *buf, int batch, int64_t n_batches, int64_t 
  * rewards (B,1), terminals (B,1), next_observations (B,O), all fp32.  idx_out may be NULL. */
 int sac_random_batch(sac_buffer_t *buf, int batch, float *obs, float *act, float *rew, float *term,
                      float *next_obs, int64_t *idx_out);
+/* The stepwise interface without a PCIe round trip per step.  The reference's loop is
+ *     train_data = replay_buffer.random_batch(bs); trainer.train(train_data)     (/root/reference/util/rlkit_custom.py:235-238)
+ * where rlkit gathers on the host and copies the batch to the device inside train().  Here random_batch can leave
+ * the batch where it is needed: sac_random_batch_device draws the next `batch` indices of the NumPy stream and
+ * gathers them into a device slot, asynchronously, and returns a token (the batch number); sac_step_device
+ * (below) runs trainer.train on it; sac_read_batch_device copies it to the host only if somebody looks at it.
+ * A token stays valid until 16 more batches have been drawn (then the calls fail with "expired"). */
+int sac_random_batch_device(sac_buffer_t *buf, int batch, int64_t *token);
+int sac_read_batch_device(sac_buffer_t *buf, int64_t token, float *obs, float *act, float *rew, float *term,
+                          float *next_obs, int64_t *idx_out);
+
 /* the gather half alone, for caller-supplied indices (parity tests, prioritised variants) */
 int sac_gather(sac_buffer_t *buf, const int64_t *idx, int batch, float *obs, float *act, float *rew,
                float *term, float *next_obs);
@@ -158,6 +169,11 @@ int sac_get_scalars(sac_trainer_t *t, double scalars[6]);
  * device counter-based stream.  diag (SAC_DIAG_N floats, may be NULL) receives this step's stats. */
 int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *rew, const float *term,
              const float *next_obs, const float *eps1, const float *eps2, float *diag);
+
+/* trainer.train(batch) on a device-resident batch (token of sac_random_batch_device on `buf`): four kernel
+ * launches behind the gather, no host copy, no synchronisation -- unless diag != NULL, which copies the step's
+ * diagnostics out (rlkit reads them on the first step of an epoch only).  Noise: the device stream. */
+int sac_step_device(sac_trainer_t *t, sac_buffer_t *buf, int64_t token, float diag[SAC_DIAG_N]);
 
 /* The whole hot loop of rlkit_custom.py:234-238 on the device:
  *   for _ in range(n_steps): batch = buffer.random_batch(B); trainer.train(batch)

@@ -6,7 +6,7 @@ Host-side mirror of the rlkit duck types the reference consumes
 over the C ABI of include/sac_hip.h.  All compute is in libsac_hip.so (HIP, gfx950);
 there is no CPU fallback."""
 from .networks import FlattenMlp, MakeDeterministic, TanhGaussianPolicy  # noqa: F401
-from .replay_buffer import EnvReplayBuffer  # noqa: F401
+from .replay_buffer import DeviceBatch, EnvReplayBuffer  # noqa: F401
 from .sac import SACTrainer  # noqa: F401
 
 __all__ = ["EnvReplayBuffer", "FlattenMlp", "TanhGaussianPolicy", "MakeDeterministic", "SACTrainer"]

@@ -57,6 +57,8 @@ SYMBOLS = {
     "sac_rng_set_state": (C.c_int, [_P, _P, C.c_int32]),
     "sac_sample_indices": (C.c_int, [_P, C.c_int, C.c_int64, _P]),
     "sac_random_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "sac_random_batch_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    "sac_read_batch_device": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "sac_gather": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "sac_sample_gather_device": (C.c_int, [_P, C.c_int, C.c_int64, _P]),
     "sac_read_slot": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
@@ -70,6 +72,7 @@ SYMBOLS = {
     "sac_set_scalars": (C.c_int, [_P, _P]),
     "sac_get_scalars": (C.c_int, [_P, _P]),
     "sac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "sac_step_device": (C.c_int, [_P, _P, C.c_int64, _P]),
     "sac_train_loop": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "sac_sync": (C.c_int, [_P]),
     "sac_last_loop_ms": (C.c_int, [_P, _F, _F, _F, _F]),

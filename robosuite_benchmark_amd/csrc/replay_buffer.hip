@@ -316,21 +316,24 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
     return 0;
 }
 
-int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset) {
+// dst == null: into b->d_idx + idx_offset (grown as needed when idx_offset == 0)
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst) {
     const int64_t count = (int64_t)batch * n_batches;
     SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
     SAC_REQUIRE(b->size - 1 <= 0xffffffffLL, "replay buffers above 2^32 slots are not supported");
-    if (idx_offset == 0 && ensure_idx(b, count)) return -1;
-    SAC_REQUIRE(idx_offset + count <= b->idx_cap, "index buffer too small for this offset");
+    if (!dst) {
+        if (idx_offset == 0 && ensure_idx(b, count)) return -1;
+        SAC_REQUIRE(idx_offset + count <= b->idx_cap, "index buffer too small for this offset");
+        dst = b->d_idx + idx_offset;
+    }
     const uint32_t rng = (uint32_t)(b->size - 1);
     if (rng == 0) {     // NumPy: no draws consumed, all zeros
-        SAC_HIP(hipMemsetAsync(b->d_idx + idx_offset, 0, sizeof(int64_t) * count, b->stream));
+        SAC_HIP(hipMemsetAsync(dst, 0, sizeof(int64_t) * count, b->stream));
         return 0;
     }
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count,
-                       b->d_idx + idx_offset);
+    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, dst);
     SAC_HIP(hipGetLastError());
     return 0;
 }
@@ -460,7 +463,10 @@ int sac_buffer_destroy(sac_buffer_t *b) {
                     (void *)b->d_rng, (void *)b->d_idx, (void *)b->d_slots})
         (void)hipFree(p);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_ring_idx);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ring_ready) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ring_free) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(b->stream);
     delete b;
     return 0;
@@ -585,6 +591,73 @@ int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *
     if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
     if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// ---- device-resident batches (the stepwise interface without a PCIe round trip per step) ----------------
+static int ensure_ring(sac_buffer *b, int batch) {
+    if (b->d_ring && b->ring_layout.B == batch) return 0;
+    SAC_HIP(hipStreamSynchronize(b->stream));
+    if (b->d_ring) { SAC_HIP(hipFree(b->d_ring)); SAC_HIP(hipFree(b->d_ring_idx)); b->d_ring = nullptr; b->d_ring_idx = nullptr; }
+    b->ring_layout = make_slot_layout(batch, b->O, b->A);
+    const size_t nfl = (size_t)b->ring_layout.slot_floats * sac_buffer::NRING;
+    SAC_HIP(hipMalloc(&b->d_ring, sizeof(float) * nfl));
+    SAC_HIP(hipMemsetAsync(b->d_ring, 0, sizeof(float) * nfl, b->stream));    // saT padding rows stay 0
+    SAC_HIP(hipMalloc(&b->d_ring_idx, sizeof(int64_t) * (size_t)batch * sac_buffer::NRING));
+    for (int i = 0; i < sac_buffer::NRING; ++i) {
+        b->ring_token[i] = -1; b->ring_in_use[i] = false;
+        if (!b->ring_ready[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_ready[i], hipEventDisableTiming));
+        if (!b->ring_free[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_free[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
+    SAC_REQUIRE(b && batch > 0 && token, "bad arguments to sac_random_batch_device");
+    SAC_HIP(hipSetDevice(b->device));
+    if (ensure_ring(b, batch)) return -1;
+    const int64_t n = b->ring_next;
+    const int slot = (int)(n % sac_buffer::NRING);
+    // the slot's previous batch may still be read by a step in flight on a trainer's stream
+    if (b->ring_in_use[slot]) { SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0)); b->ring_in_use[slot] = false; }
+    int64_t *didx = b->d_ring_idx + (size_t)slot * batch;
+    if (launch_sample(b, batch, 1, 0, didx)) return -1;
+    if (launch_gather(b, didx, batch, 1, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;
+    SAC_HIP(hipEventRecord(b->ring_ready[slot], b->stream));
+    b->ring_token[slot] = n;
+    b->ring_next = n + 1;
+    *token = n;
+    return 0;
+}
+
+// slot of a live token, or -1 (error set)
+int sac_ring_slot_of(sac_buffer_t *b, int64_t token) {
+    const int slot = (int)(token % sac_buffer::NRING);
+    if (!b || token < 0 || !b->d_ring || b->ring_token[slot] != token) {
+        sac::set_error("device batch %lld has expired: a batch stays valid until %d more have been drawn",
+                       (long long)token, sac_buffer::NRING);
+        return -1;
+    }
+    return slot;
+}
+
+int sac_read_batch_device(sac_buffer_t *b, int64_t token, float *obs, float *act, float *rew, float *term,
+                          float *next_obs, int64_t *idx_out) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    const int slot = sac_ring_slot_of(b, token);
+    if (slot < 0) return -1;
+    SAC_HIP(hipSetDevice(b->device));
+    const SlotLayout &L = b->ring_layout;
+    const float *S = b->d_ring + (size_t)slot * L.slot_floats;
+    const int B = L.B;
+    hipStream_t s = b->stream;          // in order behind the gather that filled the slot
+    if (obs) SAC_HIP(hipMemcpyAsync(obs, S + L.off_obs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, s));
+    if (act) SAC_HIP(hipMemcpyAsync(act, S + L.off_act, sizeof(float) * B * L.A, hipMemcpyDeviceToHost, s));
+    if (rew) SAC_HIP(hipMemcpyAsync(rew, S + L.off_rew, sizeof(float) * B, hipMemcpyDeviceToHost, s));
+    if (term) SAC_HIP(hipMemcpyAsync(term, S + L.off_term, sizeof(float) * B, hipMemcpyDeviceToHost, s));
+    if (next_obs) SAC_HIP(hipMemcpyAsync(next_obs, S + L.off_nobs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, s));
+    if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_ring_idx + (size_t)slot * B, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s));
+    SAC_HIP(hipStreamSynchronize(s));
     return 0;
 }
 

@@ -97,15 +97,27 @@ struct sac_buffer {
     // pinned staging
     void *h_stage = nullptr; size_t stage_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // device-resident batches of the stepwise interface (sac_random_batch_device): a ring of NRING slots; batch
+    // number n lives in slot n % NRING until batch n + NRING is drawn
+    static constexpr int NRING = 16;
+    float *d_ring = nullptr; int64_t *d_ring_idx = nullptr;
+    sac::SlotLayout ring_layout{};
+    int64_t ring_next = 0;                           // number of batches drawn so far
+    int64_t ring_token[NRING];                       // batch number held by each slot (-1: none)
+    hipEvent_t ring_ready[NRING] = {}, ring_free[NRING] = {};
+    bool ring_in_use[NRING] = {};                    // a step was launched on the slot (ring_free recorded)
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
 };
+
+// slot of a live device batch (sac_random_batch_device token), or -1 with the error set (internal)
+extern "C" int sac_ring_slot_of(sac_buffer *b, int64_t token);
 
 namespace sac {
 int ensure_stage(sac_buffer *b, size_t bytes);
 int ensure_idx(sac_buffer *b, int64_t n);
 int ensure_slots(sac_buffer *b, int B, int64_t n_slots);
 // launches on b->stream; indices stay in b->d_idx, slots in b->d_slots
-int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset = 0);
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset = 0, int64_t *dst = nullptr);
 int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
                   const SlotLayout &L, int write_saT);
 }  // namespace sac

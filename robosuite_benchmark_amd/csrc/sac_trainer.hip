@@ -1827,6 +1827,29 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     return 0;
 }
 
+// trainer.train(batch) on a device-resident batch of sac_random_batch_device: no host copy, no synchronisation
+// (diag != null: the step's diagnostics are copied out, which waits for the step).
+int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag[SAC_DIAG_N]) {
+    SAC_REQUIRE(t && b, "null argument to sac_step_device");
+    SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
+    const int slot = sac_ring_slot_of(b, token);
+    if (slot < 0) return -1;
+    SAC_REQUIRE(b->ring_layout.B == t->B, "device batch holds %d rows, the trainer was created for %d", b->ring_layout.B, t->B);
+    SAC_HIP(hipSetDevice(t->device));
+    hipStream_t s = t->stream;
+    SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[slot], 0));
+    t->dev.eps1 = t->dev.eps2 = nullptr;
+    if (launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0)) return -1;
+    SAC_HIP(hipEventRecord(b->ring_free[slot], s));
+    b->ring_in_use[slot] = true;
+    t->mirror_valid = false;
+    if (diag) {
+        SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
+        SAC_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
     SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");

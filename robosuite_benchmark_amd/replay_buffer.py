@@ -19,6 +19,56 @@ def _space_dim(space):
     return int(space)
 
 
+class DeviceBatch(dict):
+    """The dict random_batch() returns, with its arrays still in HBM.  Any read access (batch["rewards"], iteration,
+    len ...) first copies the five arrays to the host, after which it is an ordinary dict; SACTrainer.train()
+    recognises an untouched one and trains on the device copy.  The device copy lives until 16 more batches have
+    been drawn from the buffer; reading an older, never-read batch raises RuntimeError."""
+    KEYS = ("observations", "actions", "rewards", "terminals", "next_observations")
+
+    def __init__(self, buffer, token, batch_size):
+        super().__init__()
+        self._buffer, self._token, self._batch_size, self._on_host = buffer, token, batch_size, False
+
+    @property
+    def on_device(self):
+        return not self._on_host
+
+    def _fetch(self):
+        if self._on_host:
+            return
+        buf, B = self._buffer, self._batch_size
+        O, A = buf._observation_dim, buf._action_dim
+        obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)
+        act = np.empty((B, A), np.float32)
+        rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
+        _lib.check(buf._lib.sac_read_batch_device(buf._h, self._token, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
+                                                  _lib.ptr(term), _lib.ptr(nobs), None), "sac_read_batch_device")
+        self._on_host = True
+        super().update(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs)
+
+    def indices(self):
+        """The sampled buffer indices of this batch (while it is still on the device)."""
+        idx = np.empty(self._batch_size, np.int64)
+        buf = self._buffer
+        _lib.check(buf._lib.sac_read_batch_device(buf._h, self._token, None, None, None, None, None, _lib.ptr(idx)),
+                   "sac_read_batch_device")
+        return idx
+
+
+def _fetching(name):
+    def method(self, *a, **k):
+        self._fetch()
+        return getattr(dict, name)(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "__ne__", "__setitem__", "__delitem__",
+           "keys", "values", "items", "get", "copy", "pop", "update", "setdefault"):
+    setattr(DeviceBatch, _n, _fetching(_n))
+
+
 class EnvReplayBuffer:
     """``EnvReplayBuffer(max_replay_buffer_size, env)``; ``env`` only supplies
     observation_space / action_space sizes (pass ``obs_dim=`` / ``action_dim=`` instead when
@@ -26,7 +76,7 @@ class EnvReplayBuffer:
     ``seed_from_numpy()`` after ``np.random.seed`` (scripts/train.py:112) or ``seed(int)``."""
 
     def __init__(self, max_replay_buffer_size, env=None, env_info_sizes=None, obs_dim=None, action_dim=None,
-                 device=0, numpy_global_stream=False):
+                 device=0, numpy_global_stream=False, lazy_batches=True):
         if env is not None:
             obs_dim = _space_dim(env.observation_space)
             action_dim = _space_dim(env.action_space)
@@ -39,6 +89,7 @@ class EnvReplayBuffer:
         # the device, writes the advanced state back) -- exactly what rlkit's np.random.randint call does, so
         # host consumers of np.random (env resets, exploration noise) interleave identically.
         self.numpy_global_stream = bool(numpy_global_stream)
+        self.lazy_batches = bool(lazy_batches)     # random_batch() returns device-resident DeviceBatch dicts
         self._lib = _lib.load()
         h = C.c_void_p()
         _lib.check(self._lib.sac_buffer_create(C.byref(h), self._max_replay_buffer_size, self._observation_dim,
@@ -142,7 +193,22 @@ class EnvReplayBuffer:
         key = np.ascontiguousarray(st["rng_key"], dtype=np.uint32)
         _lib.check(self._lib.sac_rng_set_state(self._h, _lib.ptr(key), int(st["rng_pos"])), "sac_rng_set_state")
 
-    def random_batch(self, batch_size, return_indices=False):
+    def random_batch(self, batch_size, return_indices=False, lazy=None):
+        """rlkit's random_batch.  By default (lazy) the batch is drawn and gathered on the device and STAYS there:
+        the returned dict copies itself to the host only when somebody reads it, and SACTrainer.train() takes it
+        straight from HBM -- the reference's unmodified loop (rlkit_custom.py:235-238) then runs without a PCIe
+        round trip or a synchronisation per step.  lazy=False / return_indices=True: plain dict of host arrays."""
+        if lazy is None:
+            lazy = self.lazy_batches and not return_indices
+        if lazy:
+            if self.numpy_global_stream:
+                self.seed_from_numpy()
+            tok = C.c_int64()
+            _lib.check(self._lib.sac_random_batch_device(self._h, int(batch_size), C.byref(tok)),
+                       "sac_random_batch_device")
+            if self.numpy_global_stream:
+                self.sync_to_numpy()
+            return DeviceBatch(self, int(tok.value), int(batch_size))
         B, O, A = int(batch_size), self._observation_dim, self._action_dim
         obs, nobs = np.empty((B, O), np.float32), np.empty((B, O), np.float32)
         act = np.empty((B, A), np.float32)

@@ -110,8 +110,23 @@ class SACTrainer:
         return [self.policy, self.qf1, self.qf2, self.target_qf1, self.target_qf2]
 
     def train(self, np_batch, eps=None):
-        """TorchTrainer.train: np_to_pytorch_batch + train_from_torch (one gradient step)."""
+        """TorchTrainer.train: np_to_pytorch_batch + train_from_torch (one gradient step).
+
+        A batch that random_batch() left on the device (DeviceBatch, not read by anyone) is trained on where it
+        is: no host copy and no synchronisation; like rlkit the call then returns None, and the step's
+        diagnostics are fetched only when the epoch's statistics are due.  Host batches return the diagnostics."""
         self._num_train_steps += 1
+        if eps is None and getattr(np_batch, "on_device", False) and np_batch._buffer._h is not None:
+            B = np_batch._batch_size
+            if self._h is None or B != self._batch:
+                self._create(B)
+            diag = np.empty(_lib.SAC_DIAG_N, np.float32) if self._need_to_update_eval_statistics else None
+            _lib.check(self._lib.sac_step_device(self._h, np_batch._buffer._h, np_batch._token, _lib.ptr(diag)),
+                       "sac_step_device")
+            self._host_policy_stale = True
+            if diag is not None:
+                self._record(diag)
+            return diag
         obs = _lib.f32(np_batch["observations"])
         B = obs.shape[0]
         if self._h is None or B != self._batch:
