@@ -284,6 +284,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, A, B)
         elif world == 1:
             out["cpu_baseline"] = None
+        if world == 1:
+            # the reference's unmodified loop body (random_batch -> train) through the Python duck types, batches
+            # staying on the device (DeviceBatch): extra data point, never `value`
+            n_sw = min(args.steps, 2000)
+            for _ in range(50):
+                trainer.train(buf.random_batch(B))
+            trainer._lib.sac_sync(trainer._h)
+            t0 = time.perf_counter()
+            for _ in range(n_sw):
+                trainer.train(buf.random_batch(B))
+            trainer._lib.sac_sync(trainer._h)
+            out["stepwise_interface"] = dict(value=round(n_sw / (time.perf_counter() - t0), 2), unit="grad-steps/s", steps=n_sw,
+                                             note="replay_buffer.random_batch(B); trainer.train(batch) per step from Python")
         if world == 1 and args.replicas_per_gpu > 1:
             out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, local_rank)
     barrier()
