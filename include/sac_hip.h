@@ -129,7 +129,34 @@ typedef struct sac_config {
     int32_t reserved;
 } sac_config_t;
 
-enum { SAC_NET_POLICY = 0, SAC_NET_QF1 = 1, SAC_NET_QF2 = 2, SAC_NET_TARGET_QF1 = 3, SAC_NET_TARGET_QF2 = 4 };
+enum { SAC_NET_POLICY = 0, SAC_NET_QF1 = 1, SAC_NET_QF2 = 2, SAC_NET_TARGET_QF1 = 3, SAC_NET_TARGET_QF2 = 4,
+       SAC_NET_TARGET_POLICY = 5 /* TD3 handles only */ };
+
+/* TD3.  Replaces rlkit TD3Trainer + TanhMlpPolicy x2 as assembled at
+ * /root/reference/util/rlkit_utils.py:107-135 with the trainer kwargs of /root/reference/scripts/train.py:38-47
+ * (defaults /root/reference/util/arguments.py:141-156).  The handle type, the replay buffer and every sac_*
+ * accessor / step / loop entry point are shared with SAC: net id 5 is the target policy, both policies are
+ * [fc0, fc1, last_fc] (tanh output), sac_step's eps2 is the N(0,1) draw of the target-policy smoothing noise
+ * (eps1 unused), sac_set/get_scalars carry {policy Adam steps, 0, 0, critic Adam steps, n_train_steps_total, 0}.
+ * Diagnostics vector: slots 0-15 as for SAC (QF1/QF2 Loss, Policy Loss = -mean Q1(s, pi(s)), Q1/Q2 Predictions,
+ * Q Targets), 16-19 Bellman Errors 1, 20-23 Bellman Errors 2, 24-27 Policy Action (Mean Std Max Min).
+ * Parity: unpinned (the reference ships no TD3 run); checked against oracle/td3_step_torch.py. */
+typedef struct td3_config {
+    int32_t obs_dim, act_dim;
+    int32_t hidden;                          /* 256 */
+    int32_t batch;
+    float discount;                          /* train.py:41 fixes 0.99 */
+    float reward_scale;
+    float policy_learning_rate, qf_learning_rate;
+    float tau;                               /* soft update of all three targets, on policy steps */
+    float target_policy_noise;               /* sigma of the smoothing noise (default 0.2) */
+    float target_policy_noise_clip;          /* rlkit default 0.5 */
+    int32_t policy_and_target_update_period; /* default 2 */
+    uint64_t noise_seed;
+    int32_t device;
+    int32_t reserved;
+} td3_config_t;
+int td3_trainer_create(sac_trainer_t **out, const td3_config_t *cfg);
 
 /* diagnostics vector written per step; names = the 'trainer/...' columns of progress.csv
  * (/root/reference/runs/.../progress.csv:1) plus the optimised actor loss. */

@@ -5,8 +5,11 @@ Host-side mirror of the rlkit duck types the reference consumes
 (/root/reference/util/rlkit_utils.py:64-161, /root/reference/util/rlkit_custom.py:199-312),
 over the C ABI of include/sac_hip.h.  All compute is in libsac_hip.so (HIP, gfx950);
 there is no CPU fallback."""
-from .networks import FlattenMlp, MakeDeterministic, TanhGaussianPolicy  # noqa: F401
+from .networks import (FlattenMlp, GaussianStrategy, MakeDeterministic,  # noqa: F401
+                       PolicyWrappedWithExplorationStrategy, TanhGaussianPolicy, TanhMlpPolicy)
 from .replay_buffer import DeviceBatch, EnvReplayBuffer  # noqa: F401
 from .sac import SACTrainer  # noqa: F401
+from .td3 import TD3Trainer  # noqa: F401
 
-__all__ = ["EnvReplayBuffer", "FlattenMlp", "TanhGaussianPolicy", "MakeDeterministic", "SACTrainer"]
+__all__ = ["EnvReplayBuffer", "DeviceBatch", "FlattenMlp", "TanhGaussianPolicy", "MakeDeterministic", "SACTrainer",
+           "TD3Trainer", "TanhMlpPolicy", "GaussianStrategy", "PolicyWrappedWithExplorationStrategy"]

@@ -24,6 +24,7 @@ DIAG_NAMES = [
     "Alpha", "Alpha Loss",
 ]
 NET_IDS = {"policy": 0, "qf1": 1, "qf2": 2, "target_qf1": 3, "target_qf2": 4}
+TD3_NET_IDS = dict(NET_IDS, target_policy=5)
 
 
 class SacConfig(C.Structure):
@@ -35,6 +36,19 @@ class SacConfig(C.Structure):
         ("noise_seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
     ]
 
+
+class Td3Config(C.Structure):
+    _fields_ = [
+        ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("hidden", C.c_int32), ("batch", C.c_int32),
+        ("discount", C.c_float), ("reward_scale", C.c_float), ("policy_learning_rate", C.c_float),
+        ("qf_learning_rate", C.c_float), ("tau", C.c_float), ("target_policy_noise", C.c_float),
+        ("target_policy_noise_clip", C.c_float), ("policy_and_target_update_period", C.c_int32),
+        ("noise_seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+TD3_DIAG_NAMES = DIAG_NAMES[:16] + [f"Bellman Errors {i} {s}" for i in (1, 2) for s in ("Mean", "Std", "Max", "Min")] + [
+    f"Policy Action {s}" for s in ("Mean", "Std", "Max", "Min")]
 
 # every symbol include/sac_hip.h declares: (restype, argtypes)
 _P = C.c_void_p
@@ -63,6 +77,7 @@ SYMBOLS = {
     "sac_sample_gather_device": (C.c_int, [_P, C.c_int, C.c_int64, _P]),
     "sac_read_slot": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "sac_trainer_create": (C.c_int, [C.POINTER(_P), C.POINTER(SacConfig)]),
+    "td3_trainer_create": (C.c_int, [C.POINTER(_P), C.POINTER(Td3Config)]),
     "sac_trainer_destroy": (C.c_int, [_P]),
     "sac_param_count": (C.c_int64, [_P, C.c_int]),
     "sac_set_params": (C.c_int, [_P, C.c_int, _P, C.c_int64]),

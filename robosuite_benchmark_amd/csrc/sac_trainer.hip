@@ -39,6 +39,8 @@ constexpr float ADAM_B1 = 0.9f, ADAM_B2 = 0.999f, ADAM_EPS = 1e-8f;
 // torch computes 1 - beta in double and applies it as an fp32 scalar: (float)(1.0 - 0.9), (float)(1.0 - 0.999)
 constexpr float ADAM_1MB1 = (float)(1.0 - 0.9), ADAM_1MB2 = (float)(1.0 - 0.999);
 constexpr int DIAG_TRACE_CAP = 4096;
+// kernel variants: the SAC step, the TD3 critic pass (target policy, T1/T2, critic backward) and the TD3 actor pass
+constexpr int M_SAC = 0, M_TD3_CRITIC = 1, M_TD3_ACTOR = 2;
 constexpr int RD = 4;             // ring depth (k-chunks in flight) for the runtime-K first layers
 
 // Step counters are HOST state passed as launch arguments (a device-side counter would put a
@@ -78,8 +80,10 @@ struct Dev {
     int period, auto_alpha;
     unsigned long long noise_seed;
     Ctl *ctl;
-    // nets: 0 policy, 1 qf1, 2 qf2, 3 tqf1, 4 tqf2
-    const float *P[5];
+    // nets: 0 policy, 1 qf1, 2 qf2, 3 tqf1, 4 tqf2, 5 target policy (TD3)
+    const float *P[6];
+    int algo, sp;                  // 0 SAC, 1 TD3; column split of the step kernels (layout of qpart)
+    float td3_sigma, td3_clip;     // target-policy smoothing noise: clamp(N(0,1) * sigma, +-clip)
     const float *PT[3];
     Layer LP[3], LQ[3];
     // policy activations (s rows) feature-major [256][B]; per-row head values row-major [B][16]
@@ -526,9 +530,11 @@ __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const fl
     }
 }
 
-template <int NTH, bool WIDE, int SP>
-__global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ S, SlotLayout SL) {
-    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout)>();
+// MODE M_TD3_CRITIC: the policy blocks run the TARGET policy on s' (sq == 1) and, only when `aux` is set (policy
+// steps), the online policy on s (sq == 0); the Q blocks are the same.
+template <int NTH, bool WIDE, int SP, int MODE = M_SAC>
+__global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ S, SlotLayout SL, int aux) {
+    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + 4>();
     constexpr int NTW = 4 / SP, SW = 64 * NTW;               // tiles per wave, slice width
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
@@ -549,7 +555,8 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15;
     const int row = threadIdx.x >> 4, p16 = threadIdx.x & 15;
-    const float *P = is_pi ? d.P[0] : d.P[1 + sq];
+    if constexpr (MODE != M_SAC) { if (is_pi && sq == 0 && !aux) return; }
+    const float *P = is_pi ? ((MODE != M_SAC && sq == 1) ? d.P[5] : d.P[0]) : d.P[1 + sq];
     const Layer L0 = is_pi ? d.LP[0] : d.LQ[0], L1 = is_pi ? d.LP[1] : d.LQ[1], L2 = is_pi ? d.LP[2] : d.LQ[2];
     const int K0 = is_pi ? d.KP : d.KQ, KL0 = (K0 + 63) & ~63;
     const int n0 = SW * part + 16 * NTW * wave;              // this wave's first tile of the split layer
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         if (wave / NTW == part) {
             float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
             if (h1T) store_features<4>(keep1, 64 * wave, 16, h1T, B, row0);
-            if (!is_pi && !WIDE) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
+            if (MODE == M_SAC && !is_pi && !WIDE) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
         }
         float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
@@ -637,7 +644,10 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     STAMP(0, 4);
 }
 
-template <int NTH, bool WIDE, int SP>
+// MODE M_TD3_CRITIC: target-net blocks only (grid 2*SP*NB); the head is the TARGET policy's tanh(mean) on s' plus the
+// clipped smoothing noise.  MODE M_TD3_ACTOR: Q1(s, policy(s)) blocks only (grid SP*NB) with the unit-gradient tail;
+// the head is tanh(mean) of the online policy on s.
+template <int NTH, bool WIDE, int SP, int MODE = M_SAC>
 __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
@@ -652,8 +662,9 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     float *WL = red + 1024;              // [256][WLD]  (STAGE only)
     // XCD-aware map (see k_fwd_a): b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> T1, {6,7} -> T2
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
-    const int p4 = xr >> 1;                                          // Q1, Q2 on (s,a_new); T1, T2 on (s',a')
-    const int b = 2 * xq + (xr & 1);                                 // index inside the network's SP*NB blocks
+    // SAC: Q1, Q2 on (s,a_new); T1, T2 on (s',a').  TD3 critic pass: b % 8 in {0..3} -> T1, {4..7} -> T2.  TD3 actor: Q1.
+    const int p4 = (MODE == M_SAC) ? (xr >> 1) : (MODE == M_TD3_CRITIC ? 2 + (xr >> 2) : 0);
+    const int b = (MODE == M_SAC) ? 2 * xq + (xr & 1) : (MODE == M_TD3_CRITIC ? 4 * xq + (xr & 3) : (int)blockIdx.x);
     const int part = b % SP, rb = b / SP;
     const int side = p4 >> 1, pass = 2 + p4;
     const int row0 = rb * RB;
@@ -675,16 +686,20 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     {
         const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
         const int am = (a < A) ? a : 0;
+        const float *PH = (MODE == M_TD3_CRITIC) ? d.P[5] : d.P[0];      // head bias: target policy / online policy
 #pragma unroll
-        for (int p = 0; p < SP; ++p) { hm[p] = hp[p * (RB * 32) + am]; hr[p] = hp[p * (RB * 32) + A + am]; }
-        hbm = d.P[0][d.LP[2].offB + am];
-        hbr = d.P[0][d.LP[2].offB + A + am];
-        if (epp) epsin = epp[grow * A + am];
+        for (int p = 0; p < SP; ++p) {
+            hm[p] = hp[p * (RB * 32) + am];
+            hr[p] = (MODE == M_SAC) ? hp[p * (RB * 32) + A + am] : 0.f;  // (TD3 heads have no log-std rows)
+        }
+        hbm = PH[d.LP[2].offB + am];
+        if constexpr (MODE == M_SAC) hbr = PH[d.LP[2].offB + A + am];
+        if (MODE != M_TD3_ACTOR && epp) epsin = epp[grow * A + am];
     }
     // Q1/Q2(s, a_new) blocks (narrow first layers): launch A left the first-layer pre-activations z of Q_i(s, a) in
     // QU and the layer is linear in the action, so z + W1[:, action chunk] (a_new - a) needs only the action chunk
     // of the weights and of the input; target-net blocks do the whole layer.
-    const bool act_only = !WIDE && (p4 < 2);
+    const bool act_only = (MODE == M_SAC) && !WIDE && (p4 < 2);
     constexpr int D0 = WIDE ? RD : RD0, Q0 = D0 / 4;         // first-layer ring, issued in four pieces
     const int KS0 = d.KQ >> 4;
     const int lo0 = act_only ? KS0 - 1 : 0;                  // first chunk of the first layer this block computes
@@ -731,18 +746,30 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
 #pragma unroll
         for (int p = 1; p < SP; ++p) { mean += hm[p]; raw += hr[p]; }     // fixed order
         mean += hbm; raw += hbr;
-        lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        stdv = expf(lstd);
-        eps = epp ? epsin
-                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+        if constexpr (MODE == M_SAC) {
+            lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+            stdv = expf(lstd);
+        }
+        if constexpr (MODE != M_TD3_ACTOR)
+            eps = epp ? epsin
+                      : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
     }
     SB();
     r0.fill_part(KS0, 2 * Q0, 3 * Q0, lo0);
     r1.fill_part(H >> 4, 2 * QR, act_only ? 3 * QR : 0);
     SB();
     if (a < A) {
-        zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                      // TanhNormal.rsample
-        act = tanhf(zz);
+        if constexpr (MODE == M_SAC) {
+            zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                  // TanhNormal.rsample
+            act = tanhf(zz);
+        } else if constexpr (MODE == M_TD3_CRITIC) {
+            // TD3 target smoothing: a' + clamp(N(0,1) * sigma, +-clip); the sum is NOT clipped to the action range
+            zz = tanhf(mean);
+            act = zz + fminf(fmaxf(eps * d.td3_sigma, -d.td3_clip), d.td3_clip);
+        } else {
+            zz = mean;                                                   // pre-tanh output of the online policy
+            act = tanhf(mean);
+        }
     }
     // the whole action chunk (0 beyond A); act_only blocks contract the difference to the batch action
     XQ[lds_off(row, d.KP + a, KLQ)] = (a < A) ? (act_only ? act - abat : act) : 0.f;
@@ -750,7 +777,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     r0.fill_part(KS0, 3 * Q0, D0, lo0);
     r1.fill_part(H >> 4, act_only ? 3 * QR : 0, act_only ? RD1 : RD1 / 2);
     SB();
-    if (a < A) {
+    if (MODE == M_SAC && a < A) {
         const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
         const float var = __fmul_rn(stdv, stdv);
         const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
@@ -807,17 +834,21 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         if (own_s) {
             if (a < A) {
                 d.mu[grow * 16 + a] = mean;
-                d.ls[grow * 16 + a] = lstd;
-                d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
-                d.z[grow * 16 + a] = zz;
-                d.epsv[grow * 16 + a] = eps;
+                if constexpr (MODE == M_SAC) {
+                    d.ls[grow * 16 + a] = lstd;
+                    d.lsok[grow * 16 + a] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f;
+                    d.z[grow * 16 + a] = zz;
+                    d.epsv[grow * 16 + a] = eps;
+                }
             }
             d.anew[grow * 16 + a] = act;                      // (0 beyond A)
-            if (a == 0) d.logpi[grow] = lsum;
-            if (threadIdx.x == 0) d.part_logpi[rb] = lsum_blk;
+            if constexpr (MODE == M_SAC) {
+                if (a == 0) d.logpi[grow] = lsum;
+                if (threadIdx.x == 0) d.part_logpi[rb] = lsum_blk;
+            }
         } else if (own_n) {
             d.a2[grow * 16 + a] = act;
-            if (a == 0) d.logpi2[grow] = lsum;
+            if (MODE == M_SAC && a == 0) d.logpi2[grow] = lsum;
         }
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
@@ -872,7 +903,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // critic Q_i(s,a): y, dq = 2(q - y)/B, dL/dh2 (all features, recomputed by the SP blocks), dL/dh1 (this
 // block's features)
-template <int SP>
+template <int SP, int MODE = M_SAC>
 __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__restrict__ S, const SlotLayout &SL,
                                                  const StepArg &sa, int qi, int b) {
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
@@ -904,7 +935,8 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
             qb[p] = d.qpart[((size_t)5 * SP + p) * B + r];
             qq[p] = d.qpart[((size_t)qi * SP + p) * B + r];
         }
-        in_c = d.logpi2[r]; in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
+        if constexpr (MODE == M_SAC) in_c = d.logpi2[r];
+        in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
     }
     const int k = threadIdx.x;
     const float wk = P[d.LQ[2].offW + k];
@@ -921,7 +953,9 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     for (int t = 0; t < NTW; ++t) h1v[t] = ld4(h1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
     SB();
     // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
-    const float alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+    float alpha = 0.f;                                                   // (TD3: no entropy term in the target)
+    if constexpr (MODE == M_SAC)
+        alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
@@ -980,7 +1014,8 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
 //   dL/dz      = da*(1-a^2) + (alpha/B) * 2a(1-a^2)/(1-a^2+1e-6)
 //   dL/dmu     = dL/dz                      (the Normal terms cancel exactly under rsample)
 //   dL/dlogstd = dL/dz * std*eps - alpha/B  (masked by the clamp)
-template <int NTH, int SP>
+// MODE M_TD3_ACTOR: loss = -mean(Q1(s, tanh(mean))): da = -(1/B) dQ1/da, dL/dmean = da (1 - a^2); no log-std head.
+template <int NTH, int SP, int MODE = M_SAC>
 __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa, int b) {
     constexpr int NTW = 4 / SP, SW = 64 * NTW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1005,13 +1040,13 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
 #pragma unroll
     for (int p = 0; p < SP; ++p) {                           // Q1, Q2(s, a_new) partials of this row
         qa[p] = d.qpart[((size_t)2 * SP + p) * B + row0 + row];
-        qb[p] = d.qpart[((size_t)3 * SP + p) * B + row0 + row];
+        qb[p] = (MODE == M_SAC) ? d.qpart[((size_t)3 * SP + p) * B + row0 + row] : 0.f;
     }
     if (a < A) {
         act = d.anew[gi];
 #pragma unroll
-        for (int p = 0; p < 2 * SP; ++p) dap[p] = d.dapart[(size_t)p * B * 16 + gi];
-        lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
+        for (int p = 0; p < 2 * SP; ++p) dap[p] = (MODE == M_SAC || p < SP) ? d.dapart[(size_t)p * B * 16 + gi] : 0.f;
+        if constexpr (MODE == M_SAC) { lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi]; }
     }
     SB();
     WRing<4> rh;
@@ -1030,7 +1065,9 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     for (int t = 0; t < NTW; ++t) h1v[t] = ld4(d.PH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
-    const float alpha = alpha_step(d.ctl, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+    float alpha = 0.f;
+    if constexpr (MODE == M_SAC)
+        alpha = alpha_step(d.ctl, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     lds_barrier();
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
 #pragma unroll
@@ -1044,7 +1081,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
         for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; }                   // fixed order
         va += b3a; vb += b3b;                                                        // Q1, Q2(s, a_new)
         // torch.min backward: the smaller one takes the gradient, a tie splits it
-        const float sel1 = (va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f);
+        const float sel1 = (MODE == M_SAC) ? ((va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f)) : 1.0f;   // TD3: Q1 only
         const float dq1 = -invB * sel1, dq2 = -invB * (1.0f - sel1);
         qnew1 = va; qnew2 = vb;
         if (a < A) {
@@ -1053,11 +1090,15 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
             for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
             const float da = da1 * dq1 + da2 * dq2;
             const float om = 1.0f - act * act;
-            dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
-            const float stdv = expf(lsv);
-            dls = (dz * stdv * epv - alpha * invB) * okv;
+            if constexpr (MODE == M_SAC) {
+                dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+                const float stdv = expf(lsv);
+                dls = (dz * stdv * epv - alpha * invB) * okv;
+                XH[lds_off(row, A + a, 64)] = dls;
+            } else {
+                dz = da * om;
+            }
             XH[lds_off(row, a, 64)] = dz;
-            XH[lds_off(row, A + a, 64)] = dls;
         }
     }
     lds_barrier();
@@ -1084,7 +1125,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
             if (a == 0) { d.q[2 * (size_t)B + row0 + row] = qnew1; d.q[3 * (size_t)B + row0 + row] = qnew2; }
             if (a < A) {
                 d.dheadT[(size_t)a * B + row0 + row] = dz;
-                d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+                if constexpr (MODE == M_SAC) d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
             }
         }
         if (wave / NTW == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
@@ -1101,15 +1142,22 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
 // Block -> work map.  Three equal groups of SP*NB blocks: critic Q1, critic Q2, policy.  While they fit one
 // per CU on six XCDs (3*SP*NB <= 192) the map is XCD-aware (b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> policy,
 // {6,7} idle: an XCD's L2 pulls one network's transposed weights); larger batches use every CU instead.
-template <int NTH, int SP>
+// MODE M_TD3_CRITIC: critic blocks only (grid 2*SP*NB; b % 8 in {0..3} -> Q1, {4..7} -> Q2); M_TD3_ACTOR: policy blocks only.
+template <int NTH, int SP, int MODE = M_SAC>
 __global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa, int compact) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
-    int cls, b;
-    if (compact) { cls = (blockIdx.x & 7) >> 1; b = 2 * (blockIdx.x >> 3) + (blockIdx.x & 1); }
-    else { cls = blockIdx.x % 3; b = blockIdx.x / 3; }
-    if (cls > 2) return;
-    if (cls < 2) critic_bwd_block<SP>(d, S, SL, sa, cls, b);
-    else policy_bwd_block<NTH, SP>(d, sa, b);
+    if constexpr (MODE == M_TD3_CRITIC) {
+        critic_bwd_block<SP, MODE>(d, S, SL, sa, (blockIdx.x & 7) >> 2, 4 * (blockIdx.x >> 3) + (blockIdx.x & 3));
+    } else if constexpr (MODE == M_TD3_ACTOR) {
+        policy_bwd_block<NTH, SP, MODE>(d, sa, blockIdx.x);
+    } else {
+        int cls, b;
+        if (compact) { cls = (blockIdx.x & 7) >> 1; b = 2 * (blockIdx.x >> 3) + (blockIdx.x & 1); }
+        else { cls = blockIdx.x % 3; b = blockIdx.x / 3; }
+        if (cls > 2) return;
+        if (cls < 2) critic_bwd_block<SP>(d, S, SL, sa, cls, b);
+        else policy_bwd_block<NTH, SP>(d, sa, b);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1131,6 +1179,80 @@ __device__ __forceinline__ void adam_update(float &p, float &m, float &v, float 
 }
 
 constexpr int NSTAT = 6;     // q1, q2, q_target, log_pi, mu, log_std
+
+// TD3 statistics (rlkit TD3Trainer: QF1/QF2 Loss, Policy Loss, Q1/Q2 Predictions, Q Targets, Bellman Errors 1/2,
+// Policy Action), in the slots of the SAC vector: 16-19 Bellman Errors 1, 20-23 Bellman Errors 2, 24-27 Policy Action.
+// sa.pad bit 0: the critic part (every step, from the critic launch), bit 1: the policy part (policy / statistics
+// steps, from the launch that follows the actor pass).
+__device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa, float *red) {
+    const int B = d.B, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, loop_pos = sa.loop_pos;
+    constexpr int NS = 6;        // q1, q2, y, be1, be2, policy action
+    double sm[NS], sq[NS], lsum = 0;
+    float mx[NS], mn[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { sm[q] = 0; sq[q] = 0; mx[q] = -INFINITY; mn[q] = INFINITY; }
+    auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
+    if (sa.pad & 1)
+        for (int i = threadIdx.x; i < B; i += 256) {
+            const float yv = d.y[i], q1 = d.q[i], q2 = d.q[(size_t)B + i];
+            acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, (q1 - yv) * (q1 - yv)); acc1(4, (q2 - yv) * (q2 - yv));
+        }
+    if (sa.pad & 2) {
+        const float b3 = sload(d.P[1] + d.LQ[2].offB);
+        for (int i = threadIdx.x; i < B; i += 256) {                                             // Q1(s, policy(s))
+            float qv = d.qpart[((size_t)2 * d.sp) * B + i];
+            for (int p = 1; p < d.sp; ++p) qv += d.qpart[((size_t)2 * d.sp + p) * B + i];       // fixed order
+            lsum += (double)(qv + b3);
+            d.q[2 * (size_t)B + i] = qv + b3;
+        }
+        for (int e = threadIdx.x; e < B * d.A; e += 256) { const int i = e / d.A; acc1(5, d.anew[i * 16 + (e - i * d.A)]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            sm[q] += __shfl_xor(sm[q], o); sq[q] += __shfl_xor(sq[q], o);
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o)); mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
+        }
+        lsum += __shfl_xor(lsum, o);
+    }
+    double *sh = reinterpret_cast<double *>(red);      // [4 waves][32]
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            sh[wave * 32 + q] = sm[q]; sh[wave * 32 + 6 + q] = sq[q]; sh[wave * 32 + 12 + q] = mx[q]; sh[wave * 32 + 18 + q] = mn[q];
+        }
+        sh[wave * 32 + 24] = lsum;
+    }
+    lds_barrier();
+    auto put = [&](int di, float v) {
+        d.diag_last[di] = v;
+        if (loop_pos == 0) d.diag_first[di] = v;
+        if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
+    };
+    if (threadIdx.x < NS) {
+        const int q = threadIdx.x;
+        if ((q < 5) ? (sa.pad & 1) : (sa.pad & 2)) {
+            double s = 0, s2 = 0, MX = -INFINITY, MN = INFINITY;
+            for (int w = 0; w < 4; ++w) {
+                s += sh[w * 32 + q]; s2 += sh[w * 32 + 6 + q];
+                MX = fmax(MX, sh[w * 32 + 12 + q]); MN = fmin(MN, sh[w * 32 + 18 + q]);
+            }
+            const double cnt = (q < 5) ? (double)B : (double)B * d.A;
+            const double mean = s / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0) var = 0;
+            const int base = (q < 3) ? SAC_D_Q1_MEAN + 4 * q : SAC_D_LOGPI_MEAN + 4 * (q - 3);
+            put(base, (float)mean); put(base + 1, (float)sqrt(var)); put(base + 2, (float)MX); put(base + 3, (float)MN);
+            if (q == 3) put(SAC_D_QF1_LOSS, (float)mean);           // MSE = mean Bellman error
+            if (q == 4) put(SAC_D_QF2_LOSS, (float)mean);
+        }
+    } else if (threadIdx.x == 64 && (sa.pad & 2)) {
+        double s = 0;
+        for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24];
+        put(SAC_D_POLICY_LOSS, (float)(-s / B));
+    }
+}
 
 __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
@@ -1276,6 +1398,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
         STAMP(4, 2);
+    } else if (d.algo == 1) {
+        td3_diagnostics(d, sa, red);
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
         const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
@@ -1374,7 +1498,13 @@ struct sac_trainer {
     int device = 0;
     hipStream_t stream = nullptr;
     int B = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0, SP = 4;
-    Net net[5];
+    Net net[6];                                       // 5: TD3 target policy
+    int algo = 0;                                     // 0 SAC, 1 TD3
+    int td3_period = 2;                               // policy_and_target_update_period
+    long long adam_t_pi = 0;                          // TD3: optimizer steps of the policy (delayed)
+    DwTable dw_q{}, dw_q_tp{}, dw_pi{}, dw_none{};    // TD3 work tables: critics (without / with Polyak), policy, diagnostics only
+    void (*fwd_b2)(Dev, const float *, SlotLayout, StepArg) = nullptr;      // TD3 actor pass
+    void (*bwd2)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
     Dev dev{};
     DwTable dw{};
     DwLayer *d_dwl = nullptr;
@@ -1391,7 +1521,7 @@ struct sac_trainer {
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
     size_t lds_bw = 0;
-    void (*fwd_a)(Dev, const float *, SlotLayout) = nullptr;
+    void (*fwd_a)(Dev, const float *, SlotLayout, int) = nullptr;
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     void (*bwd)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
     size_t lds_fa = 0, lds_fb = 0;
@@ -1445,8 +1575,8 @@ struct FlatMap { int nl; int N[4], K[4]; };   // logical layers in the flat vect
 
 FlatMap flat_map(const sac_trainer *t, int netid) {
     FlatMap f{};
-    if (netid == SAC_NET_POLICY) {
-        f.nl = 4;
+    if (netid == SAC_NET_POLICY || netid == 5) {
+        f.nl = t->algo == 1 ? 3 : 4;                        // TD3: TanhMlpPolicy (one head); SAC: mean + log-std heads
         f.N[0] = H; f.K[0] = t->O; f.N[1] = H; f.K[1] = H; f.N[2] = t->A; f.K[2] = H; f.N[3] = t->A; f.K[3] = H;
     } else {
         f.nl = 3;
@@ -1469,7 +1599,7 @@ void for_each_param(const sac_trainer *t, int netid, F &&fn) {
     for (int l = 0; l < f.nl; ++l) {
         const int dl = (l < 2) ? l : 2;                       // policy heads share device layer 2
         const int nshift = (netid == SAC_NET_POLICY && l == 3) ? t->A : 0;
-        const bool qin = (netid != SAC_NET_POLICY) && l == 0;   // Q first layer: action columns start at KP
+        const bool qin = (netid >= 1 && netid <= 4) && l == 0;   // Q first layer: action columns start at KP
         for (int n = 0; n < f.N[l]; ++n)
             for (int k = 0; k < f.K[l]; ++k) fn(fi++, dl, n + nshift, (qin && k >= t->O) ? t->KP + (k - t->O) : k, false);
         for (int n = 0; n < f.N[l]; ++n) fn(fi++, dl, n + nshift, 0, true);
@@ -1485,9 +1615,45 @@ int ensure_stage_t(sac_trainer *t, size_t bytes) {
     return 0;
 }
 
+// TD3 step (rlkit TD3Trainer.train_from_torch): critic pass = 4 launches every step; on policy steps
+// (n_train_steps_total % policy_and_target_update_period == 0) the critics' Adam launch also soft-updates their
+// targets and the actor pass follows -- Q1(s, policy(s)) through the ALREADY UPDATED qf1, policy backward, policy
+// Adam + soft update of the target policy.  want_stats: also produce Policy Loss / Policy Action on a non-policy
+// step (rlkit recomputes them for the epoch statistics), without any update.
+int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j, bool want_stats) {
+    const Dev &d = t->dev;
+    hipStream_t s = t->stream;
+    const int NB = t->NB, SPv = t->SP;
+    const bool pstep = (t->n_train_steps_total % t->td3_period) == 0;
+    const bool actor = pstep || want_stats;
+    const double tq = (double)(t->adam_t + 1), tp = (double)(t->adam_t_pi + 1);
+    StepArg sq{t->n_train_steps_total, t->adam_t + 1, j, 1, 1.0 - std::pow(0.9, tq), std::sqrt(1.0 - std::pow(0.999, tq))};
+    StepArg sp{t->n_train_steps_total, t->adam_t_pi + 1, j, 2, 1.0 - std::pow(0.9, tp), std::sqrt(1.0 - std::pow(0.999, tp))};
+    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
+    hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
+    hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
+    const DwTable &Tq = pstep ? t->dw_q_tp : t->dw_q;
+    hipLaunchKernelGGL(k_dw_adam, dim3(Tq.njobs + 1), dim3(256), 0, s, d, Tq, S, sq);
+    if (actor) {
+        hipLaunchKernelGGL(t->fwd_b2, dim3(SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sp);
+        if (pstep) {
+            hipLaunchKernelGGL(t->bwd2, dim3(SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sp, 0);
+            hipLaunchKernelGGL(k_dw_adam, dim3(t->dw_pi.njobs + 1), dim3(256), 0, s, d, t->dw_pi, S, sp);
+            t->adam_t_pi += 1;
+        } else {
+            hipLaunchKernelGGL(k_dw_adam, dim3(1), dim3(256), 0, s, d, t->dw_none, S, sp);      // statistics only
+        }
+    }
+    SAC_HIP(hipGetLastError());
+    t->n_train_steps_total += 1;
+    t->adam_t += 1;
+    return 0;
+}
+
 // the four launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
 // between the launches (profiling pass only)
-int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr) {
+int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr, bool want_stats = false) {
+    if (t->algo == 1) return launch_step_td3(t, S, SL, j, want_stats);
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
     const int NB = t->NB;
@@ -1495,7 +1661,7 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
     const int SPv = t->SP;
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL);
+    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
     if (ev) SAC_HIP(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
     if (ev) SAC_HIP(hipEventRecord(ev[2], s));
@@ -1527,8 +1693,29 @@ int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
 
 extern "C" {
 
+static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td3_config_t *td3);
+
 int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     SAC_REQUIRE(out && cfg, "null argument to sac_trainer_create");
+    return trainer_create(out, cfg, nullptr);
+}
+
+// TD3 (/root/reference/util/rlkit_utils.py:107-135, scripts/train.py:38-47): the same handle
+// type and the same sac_* accessors; net id 5 is the target policy.
+int td3_trainer_create(sac_trainer_t **out, const td3_config_t *c) {
+    SAC_REQUIRE(out && c, "null argument to td3_trainer_create");
+    SAC_REQUIRE(c->policy_and_target_update_period > 0, "policy_and_target_update_period must be positive");
+    SAC_REQUIRE(c->target_policy_noise >= 0.f && c->target_policy_noise_clip >= 0.f, "negative target policy noise");
+    sac_config_t s{};
+    s.obs_dim = c->obs_dim; s.act_dim = c->act_dim; s.hidden = c->hidden; s.batch = c->batch;
+    s.discount = c->discount; s.reward_scale = c->reward_scale;
+    s.policy_lr = c->policy_learning_rate; s.qf_lr = c->qf_learning_rate;
+    s.soft_target_tau = c->tau; s.target_update_period = 1; s.use_automatic_entropy_tuning = 0;
+    s.target_entropy = 0.f; s.noise_seed = c->noise_seed; s.device = c->device;
+    return trainer_create(out, &s, c);
+}
+
+static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td3_config_t *td3) {
     *out = nullptr;
     SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
     SAC_REQUIRE(cfg->hidden == H, "hidden size %d unsupported (only 256, as in every shipped variant.json)", cfg->hidden);
@@ -1540,7 +1727,9 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     sac_trainer *t = new sac_trainer();
     t->cfg = *cfg; t->device = cfg->device;
     t->B = cfg->batch; t->O = cfg->obs_dim; t->A = cfg->act_dim;
-    t->KP = round_up(t->O, 16); t->KQ = t->KP + 16; t->NH = round_up(2 * t->A, 16);
+    t->algo = td3 ? 1 : 0;
+    if (td3) t->td3_period = td3->policy_and_target_update_period;
+    t->KP = round_up(t->O, 16); t->KQ = t->KP + 16; t->NH = round_up((td3 ? 1 : 2) * t->A, 16);
     t->NB = t->B / 16;
     // column split: small batches spread every 256-wide layer over 4 workgroups per row-block; once the
     // row-blocks alone fill the 256 CUs (B >= 512) fewer, fatter workgroups win.  SP*NB stays even (XCD map).
@@ -1554,11 +1743,12 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
 
     Arena arena;
     g_arena = &arena;
-    const int shp[3][2] = {{H, t->O}, {H, H}, {2 * t->A, H}};
+    const int shp[3][2] = {{H, t->O}, {H, H}, {(td3 ? 1 : 2) * t->A, H}};
     const int shq[3][2] = {{H, t->KQ}, {H, H}, {1, H}};     // device K of the Q first layer: padded [obs | act] layout
-    for (int i = 0; i < 5; ++i) {
+    const int nnets = td3 ? 6 : 5;
+    for (int i = 0; i < nnets; ++i) {
         Net &n = t->net[i];
-        build_layers(n, i == 0 ? shp : shq, 3);
+        build_layers(n, (i == 0 || i == 5) ? shp : shq, 3);
         if (alloc_zero(&n.P, n.nP, s)) return -1;
         if (i < 3) {
             if (alloc_zero(&n.M, n.nP, s) || alloc_zero(&n.V, n.nP, s) || alloc_zero(&n.PT, n.nPT, s) ||
@@ -1584,7 +1774,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
     arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
-    arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW);
+    arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW * 3);
     g_arena = nullptr;
     if (arena_commit(arena, &t->arena, s)) return -1;
     tot = 0;
@@ -1596,47 +1786,65 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
     d.alpha_lr = cfg->policy_lr; d.period = cfg->target_update_period;
     d.auto_alpha = cfg->use_automatic_entropy_tuning; d.noise_seed = cfg->noise_seed;
     d.ctl = t->d_ctl;
-    for (int i = 0; i < 5; ++i) d.P[i] = t->net[i].P;
+    for (int i = 0; i < 6; ++i) d.P[i] = (i < nnets) ? t->net[i].P : nullptr;
+    d.algo = t->algo; d.sp = t->SP;
+    d.td3_sigma = td3 ? td3->target_policy_noise : 0.f;
+    d.td3_clip = td3 ? td3->target_policy_noise_clip : 0.f;
     for (int i = 0; i < 3; ++i) d.PT[i] = t->net[i].PT;
     for (int l = 0; l < 3; ++l) { d.LP[l] = t->net[0].L[l]; d.LQ[l] = t->net[1].L[l]; }
     d.diag_first = t->d_diag; d.diag_last = t->d_diag + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
     d.eps1 = d.eps2 = nullptr;
 
-    // weight-gradient work table: the 256x256 layers first (longest jobs)
-    int nl = 0, job = 0;
-    std::vector<DwLayer> hl(NDW);
-    auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr) {
-        Net &n = t->net[netid];
-        const Layer &L = n.L[l];
-        t->dw.job0[nl] = job;
-        DwLayer &J = hl[nl++];
-        J.dYT = dYT; J.XT = XT; J.xt_from_slot = from_slot; J.xt_off = t->ext_layout.off_saT;
-        J.P = n.P + L.offW; J.G = n.G + L.offW;
-        J.PT = n.PT + L.offWt; J.MT = n.MT + L.offWt; J.VT = n.VT + L.offWt;
-        J.bias = n.P + L.offB; J.mb = n.M + L.offB; J.vb = n.V + L.offB; J.gb = n.G + L.offB;
-        J.TP = nullptr; J.Tbias = nullptr;
-        if (netid == 1 || netid == 2) {
-            J.TP = t->net[netid + 2].P + L.offW;
-            J.Tbias = t->net[netid + 2].P + L.offB;
-        }
-        J.ldp = L.Kp; J.ldt = L.Np; J.N = L.N; J.K = L.K; J.lr = lr;
-        J.nk = (L.Kp + 63) / 64;
-        J.job0 = job;
-        job += (L.Np / 16) * J.nk;
+    // weight-gradient work tables: the 256x256 layers first (longest jobs).  SAC: one table (3 nets).  TD3: the two
+    // critics without / with the Polyak targets (the soft update follows the critics' step on policy steps only),
+    // the policy (Polyak target = target policy), and an empty one (diagnostics block only).
+    std::vector<DwLayer> hl;
+    auto build_table = [&](DwTable &T, const std::vector<int> &nets, bool with_targets) {
+        int job = 0, nl = 0;
+        const size_t base = hl.size();
+        for (int li = 0; li < NDW; ++li) T.job0[li] = 1 << 30;
+        auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr) {
+            Net &n = t->net[netid];
+            const Layer &L = n.L[l];
+            T.job0[nl++] = job;
+            hl.emplace_back();
+            DwLayer &J = hl.back();
+            J.dYT = dYT; J.XT = XT; J.xt_from_slot = from_slot; J.xt_off = t->ext_layout.off_saT;
+            J.P = n.P + L.offW; J.G = n.G + L.offW;
+            J.PT = n.PT + L.offWt; J.MT = n.MT + L.offWt; J.VT = n.VT + L.offWt;
+            J.bias = n.P + L.offB; J.mb = n.M + L.offB; J.vb = n.V + L.offB; J.gb = n.G + L.offB;
+            J.TP = nullptr; J.Tbias = nullptr;
+            const int tgt = (netid == 0) ? (td3 ? 5 : -1) : netid + 2;
+            if (with_targets && tgt >= 0) {
+                J.TP = t->net[tgt].P + L.offW;
+                J.Tbias = t->net[tgt].P + L.offB;
+            }
+            J.ldp = L.Kp; J.ldt = L.Np; J.N = L.N; J.K = L.K; J.lr = lr;
+            J.nk = (L.Kp + 63) / 64;
+            J.job0 = job;
+            job += (L.Np / 16) * J.nk;
+        };
+        const float *dY1[3] = {d.dPH2T, d.dQH2T, d.dQH2T + (size_t)H * B}, *X1[3] = {d.PH1T, d.QH1T, d.QH1T + (size_t)H * B};
+        const float *dY0[3] = {d.dPH1T, d.dQH1T, d.dQH1T + (size_t)H * B};
+        const float *dY2[3] = {d.dheadT, d.dq16T, d.dq16T + (size_t)16 * B}, *X2[3] = {d.PH2T, d.QH2T, d.QH2T + (size_t)H * B};
+        const float lrs[3] = {cfg->policy_lr, cfg->qf_lr, cfg->qf_lr};
+        for (int n : nets) add_layer(n, 1, dY1[n], X1[n], 0, lrs[n]);
+        for (int n : nets) add_layer(n, 0, dY0[n], nullptr, 1, lrs[n]);
+        for (int n : nets) add_layer(n, 2, dY2[n], X2[n], 0, lrs[n]);
+        T.njobs = job;
+        T.L = t->d_dwl + base;
     };
-    add_layer(0, 1, d.dPH2T, d.PH1T, 0, cfg->policy_lr);
-    add_layer(1, 1, d.dQH2T, d.QH1T, 0, cfg->qf_lr);
-    add_layer(2, 1, d.dQH2T + (size_t)H * B, d.QH1T + (size_t)H * B, 0, cfg->qf_lr);
-    add_layer(0, 0, d.dPH1T, nullptr, 1, cfg->policy_lr);
-    add_layer(1, 0, d.dQH1T, nullptr, 1, cfg->qf_lr);
-    add_layer(2, 0, d.dQH1T + (size_t)H * B, nullptr, 1, cfg->qf_lr);
-    add_layer(0, 2, d.dheadT, d.PH2T, 0, cfg->policy_lr);
-    add_layer(1, 2, d.dq16T, d.QH2T, 0, cfg->qf_lr);
-    add_layer(2, 2, d.dq16T + (size_t)16 * B, d.QH2T + (size_t)H * B, 0, cfg->qf_lr);
-    t->dw.njobs = job;
-    SAC_HIP(hipMemcpyAsync(t->d_dwl, hl.data(), sizeof(DwLayer) * NDW, hipMemcpyHostToDevice, s));
+    if (!td3) build_table(t->dw, {0, 1, 2}, true);
+    else {
+        build_table(t->dw_q, {1, 2}, false);
+        build_table(t->dw_q_tp, {1, 2}, true);
+        build_table(t->dw_pi, {0}, true);
+        for (int li = 0; li < NDW; ++li) t->dw_none.job0[li] = 1 << 30;
+        t->dw_none.njobs = 0; t->dw_none.L = t->d_dwl;
+        t->dw = t->dw_q;
+    }
+    SAC_HIP(hipMemcpyAsync(t->d_dwl, hl.data(), sizeof(DwLayer) * hl.size(), hipMemcpyHostToDevice, s));
     SAC_HIP(hipStreamSynchronize(s));      // hl is a local
-    t->dw.L = t->d_dwl;
 
     const int KL0q = round_up(t->KQ, 64);
     const int nth = t->NH / 16;
@@ -1654,16 +1862,35 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg) {
                               : (wide ? &k_fwd_b<2, true, SPV> : &k_fwd_b<2, false, SPV>);                  \
         t->bwd = (nth == 1) ? &k_bwd<1, SPV> : &k_bwd<2, SPV>;                                             \
     } while (0)
-    if (t->SP == 4) SAC_PICK(4);
-    else if (t->SP == 2) SAC_PICK(2);
-    else SAC_PICK(1);
+#define TD3_PICK(SPV)                                                                                      \
+    do {                                                                                                   \
+        t->fwd_a = wide ? &k_fwd_a<1, true, SPV, M_TD3_CRITIC> : &k_fwd_a<1, false, SPV, M_TD3_CRITIC>;     \
+        t->fwd_b = wide ? &k_fwd_b<1, true, SPV, M_TD3_CRITIC> : &k_fwd_b<1, false, SPV, M_TD3_CRITIC>;     \
+        t->fwd_b2 = wide ? &k_fwd_b<1, true, SPV, M_TD3_ACTOR> : &k_fwd_b<1, false, SPV, M_TD3_ACTOR>;      \
+        t->bwd = &k_bwd<1, SPV, M_TD3_CRITIC>;                                                             \
+        t->bwd2 = &k_bwd<1, SPV, M_TD3_ACTOR>;                                                             \
+    } while (0)
+    if (!td3) {
+        if (t->SP == 4) SAC_PICK(4);
+        else if (t->SP == 2) SAC_PICK(2);
+        else SAC_PICK(1);
+    } else {
+        if (t->SP == 4) TD3_PICK(4);
+        else if (t->SP == 2) TD3_PICK(2);
+        else TD3_PICK(1);
+    }
 #undef SAC_PICK
+#undef TD3_PICK
     if (t->lds_fa > 64 * 1024)
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fa));
-    if (t->lds_fb > 64 * 1024)
+    if (t->lds_fb > 64 * 1024) {
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_b),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fb));
+        if (t->fwd_b2)
+            SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_b2),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fb));
+    }
     SAC_REQUIRE(t->lds_fb <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     SAC_HIP(hipStreamSynchronize(s));
     *out = t;
@@ -1685,7 +1912,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
 }
 
 int64_t sac_param_count(const sac_trainer_t *t, int net) {
-    if (!t || net < 0 || net > 4) return -1;
+    if (!t || net < 0 || net > (t->algo == 1 ? 5 : 4)) return -1;
     return flat_count(flat_map(t, net));
 }
 
@@ -1728,7 +1955,7 @@ static int download_padded(sac_trainer *t, int net, const float *devbuf, float *
 }
 
 int sac_set_params(sac_trainer_t *t, int net, const float *flat, int64_t n) {
-    SAC_REQUIRE(t && flat && net >= 0 && net <= 4, "bad arguments to sac_set_params");
+    SAC_REQUIRE(t && flat && net >= 0 && net <= (t->algo == 1 ? 5 : 4), "bad arguments to sac_set_params");
     SAC_REQUIRE(n == sac_param_count(t, net), "net %d expects %lld parameters, got %lld", net,
                 (long long)sac_param_count(t, net), (long long)n);
     SAC_HIP(hipSetDevice(t->device));
@@ -1737,7 +1964,7 @@ int sac_set_params(sac_trainer_t *t, int net, const float *flat, int64_t n) {
 }
 
 int sac_get_params(sac_trainer_t *t, int net, float *flat, int64_t n) {
-    SAC_REQUIRE(t && flat && net >= 0 && net <= 4, "bad arguments to sac_get_params");
+    SAC_REQUIRE(t && flat && net >= 0 && net <= (t->algo == 1 ? 5 : 4), "bad arguments to sac_get_params");
     SAC_REQUIRE(n == sac_param_count(t, net), "net %d holds %lld parameters, buffer has %lld", net,
                 (long long)sac_param_count(t, net), (long long)n);
     SAC_HIP(hipSetDevice(t->device));
@@ -1765,7 +1992,8 @@ int sac_set_scalars(sac_trainer_t *t, const double sc[6]) {
     SAC_HIP(hipSetDevice(t->device));
     Ctl c;
     memset(&c, 0, sizeof(c));
-    c.log_alpha = (float)sc[0]; c.a_m = (float)sc[1]; c.a_v = (float)sc[2];
+    if (t->algo == 1) t->adam_t_pi = (long long)sc[0];            // TD3: sc[0] = optimizer steps of the (delayed) policy
+    else { c.log_alpha = (float)sc[0]; c.a_m = (float)sc[1]; c.a_v = (float)sc[2]; }
     t->adam_t = (long long)sc[3]; t->n_train_steps_total = (long long)sc[4];
     c.alpha = t->cfg.use_automatic_entropy_tuning ? expf(c.log_alpha) : 1.0f;
     SAC_HIP(hipMemcpyAsync(t->d_ctl, &c, sizeof(c), hipMemcpyHostToDevice, t->stream));
@@ -1781,13 +2009,15 @@ int sac_get_scalars(sac_trainer_t *t, double sc[6]) {
     SAC_HIP(hipStreamSynchronize(t->stream));
     sc[0] = c.log_alpha; sc[1] = c.a_m; sc[2] = c.a_v; sc[3] = (double)t->adam_t;
     sc[4] = (double)t->n_train_steps_total; sc[5] = c.alpha;
+    if (t->algo == 1) { sc[0] = (double)t->adam_t_pi; sc[1] = sc[2] = sc[5] = 0.0; }
     return 0;
 }
 
 int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *rew, const float *term,
              const float *next_obs, const float *eps1, const float *eps2, float *diag) {
     SAC_REQUIRE(t && obs && act && rew && term && next_obs, "null batch pointer in sac_step");
-    SAC_REQUIRE((eps1 == nullptr) == (eps2 == nullptr), "eps1 and eps2 must both be given or both be NULL");
+    SAC_REQUIRE(t->algo == 1 || (eps1 == nullptr) == (eps2 == nullptr), "eps1 and eps2 must both be given or both be NULL");
+    if (t->algo == 1) eps1 = eps2;                       // TD3 draws one noise tensor (target smoothing): eps2
     SAC_HIP(hipSetDevice(t->device));
     const int B = t->B, O = t->O, A = t->A;
     const SlotLayout &L = t->ext_layout;
@@ -1820,7 +2050,7 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     } else {
         t->dev.eps1 = t->dev.eps2 = nullptr;
     }
-    if (launch_step(t, t->ext_slot, L, 0)) return -1;
+    if (launch_step(t, t->ext_slot, L, 0, nullptr, diag != nullptr)) return -1;
     if (diag) SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
     t->mirror_valid = false;
@@ -1839,7 +2069,7 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     hipStream_t s = t->stream;
     SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[slot], 0));
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    if (launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0)) return -1;
+    if (launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr)) return -1;
     SAC_HIP(hipEventRecord(b->ring_free[slot], s));
     b->ring_in_use[slot] = true;
     t->mirror_valid = false;
@@ -1882,7 +2112,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         SAC_HIP(hipEventRecord(t->ev_ready[half], b->stream));
         SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[half], 0));
         for (int64_t i = 0; i < m; ++i)
-            if (launch_step(t, b->d_slots + (size_t)(slot0 + i) * b->slot.slot_floats, b->slot, (int)(first + i))) return -1;
+            if (launch_step(t, b->d_slots + (size_t)(slot0 + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
         SAC_HIP(hipEventRecord(t->ev_done[half], s));
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
@@ -1899,6 +2129,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
 
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[9]) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
+    SAC_REQUIRE(t->algo == 0, "sac_profile_loop instruments the SAC step only");
     SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
@@ -2023,7 +2254,8 @@ int sac_policy_mirror(sac_trainer_t *t) {
 
 int sac_policy_act(sac_trainer_t *t, const float *obs, int deterministic, const float *eps, float *act) {
     SAC_REQUIRE(t && obs && act, "bad arguments to sac_policy_act");
-    SAC_REQUIRE(deterministic || eps, "stochastic acting needs the N(0,1) draw (eps)");
+    SAC_REQUIRE(deterministic || eps || t->algo == 1, "stochastic acting needs the N(0,1) draw (eps)");
+    if (t->algo == 1) deterministic = 1;        // TanhMlpPolicy: tanh(last_fc); exploration noise is the caller's strategy
     if (!t->mirror_valid && sac_policy_mirror(t)) return -1;
     const int O = t->O, A = t->A;
     const float *p = t->h_policy.data();
@@ -2041,10 +2273,12 @@ int sac_policy_act(sac_trainer_t *t, const float *obs, int deterministic, const 
         h2[n] = s > 0.f ? s : 0.f;
     }
     for (int a = 0; a < A; ++a) {
-        float m = bm[a], ls = bs[a];
-        for (int k = 0; k < H; ++k) { m += Wm[(size_t)a * H + k] * h2[k]; ls += Ws[(size_t)a * H + k] * h2[k]; }
+        float m = bm[a], ls = 0.f;
+        for (int k = 0; k < H; ++k) m += Wm[(size_t)a * H + k] * h2[k];
         if (deterministic) act[a] = tanhf(m);
         else {
+            ls = bs[a];
+            for (int k = 0; k < H; ++k) ls += Ws[(size_t)a * H + k] * h2[k];
             ls = fminf(fmaxf(ls, LOG_SIG_MIN), LOG_SIG_MAX);
             act[a] = tanhf(m + expf(ls) * eps[a]);
         }

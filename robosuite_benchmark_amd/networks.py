@@ -131,3 +131,65 @@ class MakeDeterministic:
 
     def train(self, mode=True):
         return self
+
+
+class TanhMlpPolicy(_Mlp):
+    """``TanhMlpPolicy(input_size=, output_size=, hidden_sizes=)`` (rlkit_utils.py:108-117, the TD3 actor and its
+    target): relu MLP with a tanh output; ``get_action(obs_np)`` returns ``(action, {})``."""
+
+    def __init__(self, hidden_sizes, output_size, input_size, init_w=1e-3, **kwargs):
+        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"))
+        self.obs_dim, self.action_dim = int(input_size), int(output_size)
+
+    def get_actions(self, obs_np):
+        if self._trainer is not None:
+            self._trainer.refresh_host_policy()
+        h = np.asarray(obs_np, np.float32)
+        names = list(self.layers)
+        for n in names[:-1]:
+            w, b = self.layers[n]
+            h = np.maximum(h @ w.T + b, 0)
+        w, b = self.layers[names[-1]]
+        return np.tanh(h @ w.T + b)
+
+    def get_action(self, obs_np):
+        return self.get_actions(np.asarray(obs_np)[None])[0, :], {}
+
+    def reset(self):
+        pass
+
+
+class GaussianStrategy:
+    """rlkit GaussianStrategy(action_space, max_sigma, min_sigma) with constant sigma as the reference uses it
+    (rlkit_utils.py:118-122: max_sigma = min_sigma = 0.1): action + N(0, sigma), clipped to the action box."""
+
+    def __init__(self, action_space=None, max_sigma=1.0, min_sigma=None, decay_period=1000000, low=-1.0, high=1.0,
+                 seed=0):
+        self._max_sigma = float(max_sigma)
+        self._min_sigma = float(max_sigma if min_sigma is None else min_sigma)
+        self._decay_period = int(decay_period)
+        self.low = getattr(action_space, "low", low)
+        self.high = getattr(action_space, "high", high)
+        self._rs = np.random.RandomState(seed)
+
+    def get_action_from_raw_action(self, action, t=None):
+        frac = min(1.0, (t or 0) * 1.0 / self._decay_period)
+        sigma = self._max_sigma - (self._max_sigma - self._min_sigma) * frac
+        return np.clip(action + self._rs.standard_normal(len(action)) * sigma, self.low, self.high).astype(np.float32)
+
+
+class PolicyWrappedWithExplorationStrategy:
+    """``PolicyWrappedWithExplorationStrategy(exploration_strategy=, policy=)`` (rlkit_utils.py:123-126)."""
+
+    def __init__(self, exploration_strategy, policy):
+        self.es, self.policy, self.t = exploration_strategy, policy, 0
+
+    def get_action(self, *args, **kwargs):
+        action, info = self.policy.get_action(*args, **kwargs)
+        return self.es.get_action_from_raw_action(action, self.t), info
+
+    def reset(self):
+        self.policy.reset()
+
+    def set_num_steps_total(self, t):
+        self.t = t

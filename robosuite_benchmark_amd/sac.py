@@ -43,20 +43,26 @@ class SACTrainer:
             self._create(int(batch_size))
 
     # ---- handle management -----------------------------------------------------------------
-    def _create(self, batch):
-        hs = self.policy.hidden_sizes
-        if list(hs) != [256, 256] or list(self.qf1.hidden_sizes) != [256, 256]:
-            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements the benchmark's [256, 256]")
+    NETS = NET_IDS                           # name -> C net id (TD3Trainer adds target_policy)
+
+    def _new_handle(self, batch):
         cfg = SacConfig(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale, self.policy_lr,
                         self.qf_lr, self.soft_target_tau, self.target_update_period,
                         int(self.use_automatic_entropy_tuning), self.target_entropy, self.noise_seed, self.device, 0)
         h = C.c_void_p()
         _lib.check(self._lib.sac_trainer_create(C.byref(h), C.byref(cfg)), "sac_trainer_create")
+        return h
+
+    def _create(self, batch):
+        hs = self.policy.hidden_sizes
+        if list(hs) != [256, 256] or list(self.qf1.hidden_sizes) != [256, 256]:
+            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements the benchmark's [256, 256]")
+        h = self._new_handle(batch)
         state = self._export_state() if self._h else None
         self._destroy()
         self._h, self._batch = h, batch
         if state is None:
-            for name in NET_IDS:
+            for name in self.NETS:
                 self._set_params(name, getattr(self, name).flat())
         else:
             self._import_state(state)
@@ -71,16 +77,16 @@ class SACTrainer:
 
     def _set_params(self, name, flat):
         flat = _lib.f32(flat)
-        _lib.check(self._lib.sac_set_params(self._h, NET_IDS[name], _lib.ptr(flat), flat.size), "sac_set_params")
+        _lib.check(self._lib.sac_set_params(self._h, self.NETS[name], _lib.ptr(flat), flat.size), "sac_set_params")
 
     def _get_params(self, name):
-        n = int(self._lib.sac_param_count(self._h, NET_IDS[name]))
+        n = int(self._lib.sac_param_count(self._h, self.NETS[name]))
         out = np.empty(n, np.float32)
-        _lib.check(self._lib.sac_get_params(self._h, NET_IDS[name], _lib.ptr(out), n), "sac_get_params")
+        _lib.check(self._lib.sac_get_params(self._h, self.NETS[name], _lib.ptr(out), n), "sac_get_params")
         return out
 
     def _export_state(self):
-        st = dict(params={k: self._get_params(k) for k in NET_IDS}, opt={})
+        st = dict(params={k: self._get_params(k) for k in self.NETS}, opt={})
         for k in ("policy", "qf1", "qf2"):
             n = st["params"][k].size
             m, v = np.empty(n, np.float32), np.empty(n, np.float32)
@@ -136,7 +142,7 @@ class SACTrainer:
         term = _lib.f32(np.asarray(np_batch["terminals"]).reshape(B))
         e1 = e2 = None
         if eps is not None:
-            e1, e2 = _lib.f32(eps[0]), _lib.f32(eps[1])
+            e1, e2 = (None if e is None else _lib.f32(e) for e in eps)
         diag = np.empty(_lib.SAC_DIAG_N, np.float32)
         _lib.check(self._lib.sac_step(self._h, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew), _lib.ptr(term),
                                       _lib.ptr(nobs), _lib.ptr(e1), _lib.ptr(e2), _lib.ptr(diag)), "sac_step")
@@ -196,7 +202,7 @@ class SACTrainer:
             self._host_policy_stale = False
 
     def sync_networks_to_host(self):
-        for name in NET_IDS:
+        for name in self.NETS:
             getattr(self, name).load_flat(self._get_params(name))
         self._host_policy_stale = False
 

@@ -81,3 +81,23 @@ def make_pair_from_flat(flats, O, A, B, device=0, **kw):
     hip = SACTrainer(policy=pol, qf1=qn[0], qf2=qn[1], target_qf1=qn[2], target_qf2=qn[3], batch_size=B,
                      device=device, noise_seed=noise_seed, **kw)
     return oracle, hip
+
+
+def make_td3_pair(O, A, B, seed=3, device=0, **kw):
+    """A TD3 oracle and a HIP TD3 trainer holding identical parameters."""
+    from oracle.td3_step_torch import RlkitEquivalentTD3, init_td3_params
+    from robosuite_benchmark_amd import FlattenMlp, TanhMlpPolicy, TD3Trainer
+    kw.setdefault("policy_learning_rate", 1e-3)
+    kw.setdefault("qf_learning_rate", 5e-4)
+    nets = init_td3_params(O, A, seed=seed)
+    noise_seed = kw.pop("noise_seed", 0)
+    oracle = RlkitEquivalentTD3(nets, A, **kw)
+    pols = [TanhMlpPolicy([256, 256], A, O) for _ in range(2)]
+    qs = [FlattenMlp([256, 256], 1, O + A) for _ in range(4)]
+    for p, name in zip(pols, ("policy", "target_policy")):
+        p.load_flat(flat_of(nets[name]))
+    for q, name in zip(qs, ("qf1", "qf2", "target_qf1", "target_qf2")):
+        q.load_flat(flat_of(nets[name]))
+    hip = TD3Trainer(policy=pols[0], qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], target_policy=pols[1],
+                     batch_size=B, device=device, noise_seed=noise_seed, **kw)
+    return oracle, hip

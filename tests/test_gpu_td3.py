@@ -1,0 +1,115 @@
+"""GPU parity of the TD3 step against oracle/td3_step_torch.py (rlkit-equivalent restatement;
+parity unpinned: the reference ships no TD3 number).  Tolerances as for SAC: logged scalars 1e-5 * max(1, |b|)."""
+import numpy as np
+import pytest
+
+from robosuite_benchmark_amd import EnvReplayBuffer
+from robosuite_benchmark_amd._lib import TD3_DIAG_NAMES
+from tests.helpers import flat_of, make_td3_pair, rel_err, synth_transitions
+
+pytestmark = pytest.mark.gpu
+
+
+def batch_and_noise(B, O, A, seed, term_frac=0.1):
+    obs, act, rew, term, nobs = synth_transitions(B, O, A, seed=seed, term_frac=term_frac)
+    eps = np.random.RandomState(seed + 1).standard_normal((B, A)).astype(np.float32)
+    return dict(observations=obs, actions=act, rewards=rew, terminals=term.astype(np.float32), next_observations=nobs), eps
+
+
+def check_diag(diag, want, policy=True):
+    for i, name in enumerate(TD3_DIAG_NAMES):
+        if name in want and (policy or not name.startswith("Policy")):
+            assert abs(float(diag[i]) - want[name]) <= 1e-5 * max(1.0, abs(want[name])), (name, float(diag[i]), want[name])
+
+
+def scale_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(1e-30, np.max(np.abs(want))))
+
+
+@pytest.mark.parametrize("O,A,B", [(42, 7, 256), (46, 7, 1024), (89, 14, 256), (379, 6, 64), (11, 3, 512), (5, 2, 16)])
+def test_policy_step_from_identical_state(O, A, B):
+    oracle, hip = make_td3_pair(O, A, B, seed=11)
+    nb, eps = batch_and_noise(B, O, A, seed=21)
+    want = oracle.step(nb["observations"], nb["actions"], nb["rewards"], nb["terminals"], nb["next_observations"], eps)
+    diag = hip.train(nb, eps=eps)                          # step 0 is a policy step
+    check_diag(diag, want)
+    L = oracle.last
+    for name, ref in (("a_next", L["noisy"]), ("a_new", L["pa"])):
+        assert scale_err(hip.debug_fetch(name, B * A), ref.detach().numpy().ravel()) < 2e-5, name
+    for name, ref in (("q1", L["q1"]), ("q2", L["q2"]), ("q_target", L["y"]), ("tq1", L["tq1"]), ("tq2", L["tq2"]),
+                      ("q1_new", L["q_pi"])):
+        assert rel_err(hip.debug_fetch(name, B), ref.detach().numpy().ravel()) < 2e-5, name
+    for g in ("g_qf1", "g_qf2", "g_policy"):
+        assert scale_err(hip.debug_fetch(g, L[g].size), L[g]) < 5e-5, g
+    # parameters after the step: Adam's first step is +-lr per element, compare to a fraction of lr; targets exactly Polyak
+    nets = oracle.export_nets()
+    got = hip.state_dict()["params"]
+    for name, lr in (("qf1", 5e-4), ("qf2", 5e-4), ("policy", 1e-3)):
+        d = np.abs(got[name] - flat_of(nets[name]))
+        assert np.mean(d > 0.1 * lr) < 2e-3, name          # sign flips only where the gradient is ~0
+    for name in ("target_qf1", "target_qf2", "target_policy"):
+        assert np.max(np.abs(got[name] - flat_of(nets[name]))) < 2e-5, name
+
+
+def test_five_steps_track_the_oracle_with_delayed_updates():
+    O, A, B = 42, 7, 128
+    oracle, hip = make_td3_pair(O, A, B, seed=5, policy_and_target_update_period=2)
+    pol0 = hip.state_dict()["params"]["policy"].copy()
+    for step in range(5):
+        nb, eps = batch_and_noise(B, O, A, seed=100 + step)
+        want = oracle.step(nb["observations"], nb["actions"], nb["rewards"], nb["terminals"], nb["next_observations"], eps)
+        before = hip.state_dict()["params"]
+        diag = hip.train(nb, eps=eps)
+        after = hip.state_dict()["params"]
+        pstep = step % 2 == 0
+        for i, name in enumerate(TD3_DIAG_NAMES):            # trajectories drift apart slowly (Adam sign flips): 1e-3
+            if name in want:
+                assert abs(float(diag[i]) - want[name]) <= 1e-3 * max(1.0, abs(want[name])), (step, name)
+        for name in ("policy", "target_policy", "target_qf1", "target_qf2"):
+            assert np.array_equal(before[name], after[name]) == (not pstep), (step, name)
+        assert not np.array_equal(before["qf1"], after["qf1"])
+    assert not np.array_equal(pol0, hip.state_dict()["params"]["policy"])
+    sc = hip.state_dict()["scalars"]
+    assert (sc[0], sc[3], sc[4]) == (3.0, 5.0, 5.0)          # policy Adam steps, critic Adam steps, train steps
+
+
+def test_fused_loop_equals_stepwise_and_device_batches():
+    O, A, B, steps, n = 42, 7, 256, 21, 6000
+    _, fused = make_td3_pair(O, A, B, seed=4, noise_seed=7)
+    _, stepw = make_td3_pair(O, A, B, seed=4, noise_seed=7)
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=8)
+    bufs = []
+    for _ in range(2):
+        b = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
+        b.add_block(obs, act, rew, nobs, term)
+        b.seed(17)
+        bufs.append(b)
+    first, last = fused.train_loop(bufs[0], steps, batch_size=B)
+    outs = [stepw.train(bufs[1].random_batch(B)) for _ in range(steps)]
+    assert outs[0] is not None and np.array_equal(outs[0], first)
+    sa, sb = fused.state_dict(), stepw.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    for k in sa["opt"]:
+        assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
+    assert np.all(np.isfinite(last[:28]))
+
+
+def test_learning_and_snapshot_keys():
+    O, A, B = 11, 3, 64
+    _, hip = make_td3_pair(O, A, B, seed=9, noise_seed=1)
+    obs, act, rew, term, nobs = synth_transitions(3000, O, A, seed=3)
+    buf = EnvReplayBuffer(3000, obs_dim=O, action_dim=A)
+    buf.add_block(obs, act, rew, nobs, term)
+    buf.seed(1)
+    first, last = hip.train_loop(buf, 400, batch_size=B)
+    i = TD3_DIAG_NAMES.index
+    assert last[i("QF1 Loss")] < first[i("QF1 Loss")]
+    assert last[i("Policy Loss")] < first[i("Policy Loss")]      # the actor climbs Q1
+    snap = hip.get_snapshot()
+    assert {"policy", "qf1", "qf2", "target_qf1", "target_qf2", "target_policy", "trained_policy"} <= set(snap)
+    a, _ = snap["trained_policy"].get_action(obs[0])
+    assert a.shape == (A,) and np.all(np.abs(a) <= 1)
+    assert set(hip.get_diagnostics()) >= {"QF1 Loss", "Policy Loss", "Bellman Errors 1 Mean", "Policy Action Max"}
