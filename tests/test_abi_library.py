@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert n in _lib.SYMBOLS, f"{n} has no ctypes signature in _lib.SYMBOLS"
     assert set(_lib.SYMBOLS) == set(names)
     nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
-    exported = set(re.findall(r" T (sac_[a-z0-9_]+)", nm))
+    exported = set(re.findall(r" T ((?:sac|td3)_[a-z0-9_]+)", nm))
     assert set(names) <= exported
     assert lib.sac_version().startswith(b"sac_hip")
 
