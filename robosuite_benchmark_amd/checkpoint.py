@@ -80,7 +80,7 @@ def load_checkpoint(dirname, trainer, replay_buffer=None):
         raise ValueError("checkpointed trainer has other dimensions")
     if trainer._h is None:
         trainer._create(int(tm["batch_size"]))
-    st = dict(params={n: arr(f"params.{n}") for n in NETS},
+    st = dict(params={n: arr(f"params.{n}") for n in trainer.NETS},
               opt={n: (arr(f"adam_m.{n}"), arr(f"adam_v.{n}")) for n in ("policy", "qf1", "qf2")},
               scalars=arr("trainer_scalars"))
     trainer.load_state_dict(st)
@@ -96,9 +96,9 @@ def load_checkpoint(dirname, trainer, replay_buffer=None):
 
 
 # ---- the reference's own checkpoint files ----------------------------------------------------------------
-def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256)):
-    """(name, shape) of every parameter in rlkit's registration order (Mlp: fc0.., last_fc; policy adds
-    last_fc_log_std) -- the order torch.save numbers the storages in."""
+def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256), agent="SAC"):
+    """(name, shape) of every parameter in rlkit's registration order (Mlp: fc0.., last_fc; the SAC policy adds
+    last_fc_log_std, the TD3 TanhMlpPolicy does not) -- the order torch.save numbers the storages in."""
     def mlp(inp, outs):
         names, k = [], inp
         for i, h in enumerate(hidden):
@@ -107,7 +107,8 @@ def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256)):
         for head, n in outs:
             names += [(f"{head}.weight", (n, k)), (f"{head}.bias", (n,))]
         return names
-    return OrderedDict(policy=mlp(obs_dim, [("last_fc", action_dim), ("last_fc_log_std", action_dim)]),
+    heads = [("last_fc", action_dim)] + ([("last_fc_log_std", action_dim)] if agent == "SAC" else [])
+    return OrderedDict(policy=mlp(obs_dim, heads),
                        qf1=mlp(obs_dim + action_dim, [("last_fc", 1)]),
                        qf2=mlp(obs_dim + action_dim, [("last_fc", 1)]))
 
@@ -142,10 +143,10 @@ def export_torch_state_dicts(path, source, obs_dim=None, action_dim=None):
         st = source
     else:
         st, obs_dim, action_dim = source.state_dict()["params"], source.obs_dim, source.act_dim
-    shapes = rlkit_layer_shapes(obs_dim, action_dim)
-    shapes["target_qf1"], shapes["target_qf2"] = shapes["qf1"], shapes["qf2"]
+    shapes = rlkit_layer_shapes(obs_dim, action_dim, agent="TD3" if "target_policy" in st else "SAC")
+    shapes["target_qf1"], shapes["target_qf2"], shapes["target_policy"] = shapes["qf1"], shapes["qf2"], shapes["policy"]
     out = OrderedDict()
-    for net in NETS:
+    for net in NETS + ("target_policy",):
         if net not in st:
             continue
         flat, off, sd = np.asarray(st[net], np.float32), 0, OrderedDict()

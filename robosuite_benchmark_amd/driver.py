@@ -17,9 +17,11 @@ from collections import OrderedDict
 import numpy as np
 
 from .checkpoint import load_checkpoint, save_checkpoint
-from .networks import FlattenMlp, MakeDeterministic, TanhGaussianPolicy
+from .networks import (FlattenMlp, GaussianStrategy, MakeDeterministic, PolicyWrappedWithExplorationStrategy,
+                       TanhGaussianPolicy, TanhMlpPolicy)
 from .replay_buffer import EnvReplayBuffer
 from .sac import SACTrainer
+from .td3 import TD3Trainer
 from .variant import env_dims, validate
 
 
@@ -137,12 +139,22 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
     expl_env = SyntheticEnv(O, A, variant["expl_environment_kwargs"].get("horizon", 500), seed)
     eval_env = SyntheticEnv(O, A, variant["eval_environment_kwargs"].get("horizon", 500), seed + 1)
     qf1, qf2, tqf1, tqf2 = (FlattenMlp(input_size=O + A, output_size=1, **variant["qf_kwargs"]) for _ in range(4))
-    policy = TanhGaussianPolicy(obs_dim=O, action_dim=A, **variant["policy_kwargs"])
-    eval_policy = MakeDeterministic(policy)
-    trainer = SACTrainer(env=eval_env, policy=policy, qf1=qf1, qf2=qf2, target_qf1=tqf1, target_qf2=tqf2,
-                         batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
+    if variant.get("algorithm", "SAC") == "TD3":                  # rlkit_utils.py:107-135
+        policy = TanhMlpPolicy(input_size=O, output_size=A, **variant["policy_kwargs"])
+        target_policy = TanhMlpPolicy(input_size=O, output_size=A, **variant["policy_kwargs"])
+        eval_policy = policy
+        expl_policy = PolicyWrappedWithExplorationStrategy(
+            exploration_strategy=GaussianStrategy(max_sigma=0.1, min_sigma=0.1, seed=seed), policy=policy)
+        trainer = TD3Trainer(policy=policy, qf1=qf1, qf2=qf2, target_qf1=tqf1, target_qf2=tqf2, target_policy=target_policy,
+                             batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
+        policy._noise = expl_policy.es._rs                        # (the generator a checkpoint saves as policy_noise)
+    else:
+        policy = TanhGaussianPolicy(obs_dim=O, action_dim=A, **variant["policy_kwargs"])
+        eval_policy, expl_policy = MakeDeterministic(policy), policy
+        trainer = SACTrainer(env=eval_env, policy=policy, qf1=qf1, qf2=qf2, target_qf1=tqf1, target_qf2=tqf2,
+                             batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
     buf = EnvReplayBuffer(variant["replay_buffer_size"], obs_dim=O, action_dim=A, device=device)
-    expl, evalc = PathCollector(expl_env, policy), PathCollector(eval_env, eval_policy)
+    expl, evalc = PathCollector(expl_env, expl_policy), PathCollector(eval_env, eval_policy)
     rows, t_start = [], time.time()
     writer, fh = None, None
     first_epoch = 0
@@ -214,7 +226,7 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
             fh.flush()
         if not quiet:
             print(f"epoch {epoch}: buffer {row['replay_buffer/size']}  QF1 {row['trainer/QF1 Loss']:.4f}  "
-                  f"alpha {row['trainer/Alpha']:.4f}  training {row['time/training (s)']:.3f}s "
+                  f"policy loss {row['trainer/Policy Loss']:.4f}  training {row['time/training (s)']:.3f}s "
                   f"({n_train / max(row['time/training (s)'], 1e-9):.0f} steps/s)", flush=True)
     if fh:
         fh.close()

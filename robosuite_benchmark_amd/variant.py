@@ -26,10 +26,17 @@ def load_variant(path):
 
 
 def default_variant(env="Lift", robots=("Panda",), controller="OSC_POSE", seed=1, batch_size=256,
-                    target_update_period=1):
-    """The dict scripts/train.py:53-77 builds from the argparse defaults (arguments.py)."""
+                    target_update_period=1, agent="SAC"):
+    """The dict scripts/train.py:53-77 builds from the argparse defaults (arguments.py); agent "TD3": the trainer
+    kwargs of scripts/train.py:38-47 with the defaults of arguments.py:141-156."""
     envkw = dict(env_name=env, robots=list(robots), horizon=500, control_freq=20, controller=controller,
                  reward_scale=1.0, hard_reset=False, ignore_done=True)
+    if agent == "TD3":
+        v = default_variant(env, robots, controller, seed, batch_size, target_update_period)
+        v["algorithm"] = "TD3"
+        v["trainer_kwargs"] = dict(target_policy_noise=0.2, discount=0.99, reward_scale=1.0, policy_learning_rate=1e-3,
+                                   qf_learning_rate=5e-4, policy_and_target_update_period=2, tau=0.005)
+        return v
     return dict(
         algorithm="SAC", seed=seed, version="normal", replay_buffer_size=int(1e6),
         qf_kwargs=dict(hidden_sizes=[256, 256]), policy_kwargs=dict(hidden_sizes=[256, 256]),
@@ -57,8 +64,8 @@ def env_dims(env_kwargs, obs_dim=None, action_dim=None):
 
 def validate(variant):
     """The checks the reference does implicitly (KeyError / assert at rlkit_utils.py:34)."""
-    if variant.get("algorithm", "SAC") != "SAC":
-        raise ValueError(f"agent {variant.get('algorithm')!r}: only SAC is on the MI355X hot path (TD3 is out of scope)")
+    if variant.get("algorithm", "SAC") not in ("SAC", "TD3"):
+        raise ValueError(f"agent {variant.get('algorithm')!r}: the reference knows SAC and TD3 (rlkit_utils.py:91-137)")
     for k in ("replay_buffer_size", "qf_kwargs", "policy_kwargs", "algorithm_kwargs", "trainer_kwargs",
               "expl_environment_kwargs", "eval_environment_kwargs"):
         if k not in variant:

@@ -19,12 +19,13 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--env", type=str, default="Lift")
     ap.add_argument("--batch_size", type=int, default=256)
+    ap.add_argument("--agent", type=str, default="SAC", choices=["SAC", "TD3"])
     ap.add_argument("--resume", type=str, default=None,
                     help="an existing run directory (…_0000--s-0): continue it from its checkpoint/ after the last saved epoch")
     ap.add_argument("--no_checkpoint", action="store_true", help="do not save <run_dir>/checkpoint after every epoch")
     args = ap.parse_args()
     variant = load_variant(args.variant) if args.variant else default_variant(env=args.env, seed=args.seed,
-                                                                              batch_size=args.batch_size)
+                                                                              batch_size=args.batch_size, agent=args.agent)
     run_dir = None
     if args.resume:
         import json
