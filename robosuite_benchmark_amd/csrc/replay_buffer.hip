@@ -431,6 +431,8 @@ int sac_device_count(void) {
     return n;
 }
 
+static int buffer_build(sac_buffer *b, int64_t capacity, int obs_dim, int act_dim, int device);
+
 int sac_buffer_create(sac_buffer_t **out, int64_t capacity, int obs_dim, int act_dim, int device) {
     SAC_REQUIRE(out != nullptr, "null out pointer");
     *out = nullptr;
@@ -439,6 +441,15 @@ int sac_buffer_create(sac_buffer_t **out, int64_t capacity, int obs_dim, int act
     SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
     SAC_HIP(hipSetDevice(device));
     sac_buffer *b = new sac_buffer();
+    if (buffer_build(b, capacity, obs_dim, act_dim, device)) {     // (the error message is already set)
+        sac_buffer_destroy(b);
+        return -1;
+    }
+    *out = b;
+    return 0;
+}
+
+static int buffer_build(sac_buffer *b, int64_t capacity, int obs_dim, int act_dim, int device) {
     b->device = device;
     b->capacity = capacity;
     b->O = obs_dim; b->A = act_dim;
@@ -451,14 +462,13 @@ int sac_buffer_create(sac_buffer_t **out, int64_t capacity, int obs_dim, int act
     SAC_HIP(hipMalloc(&b->term, sizeof(float) * capacity));
     SAC_HIP(hipMalloc(&b->d_rng, sizeof(MtState)));
     for (auto &e : b->ev) SAC_HIP(hipEventCreate(&e));
-    *out = b;
     return sac_rng_seed(b, 5489u);
 }
 
 int sac_buffer_destroy(sac_buffer_t *b) {
     if (!b) return 0;
     (void)hipSetDevice(b->device);
-    (void)hipStreamSynchronize(b->stream);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
     for (void *p : {(void *)b->obs, (void *)b->nobs, (void *)b->act, (void *)b->rew, (void *)b->term,
                     (void *)b->d_rng, (void *)b->d_idx, (void *)b->d_slots})
         (void)hipFree(p);
@@ -467,7 +477,7 @@ int sac_buffer_destroy(sac_buffer_t *b) {
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_free) if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(b->stream);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return 0;
 }

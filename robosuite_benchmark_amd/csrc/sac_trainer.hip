@@ -26,6 +26,7 @@
 #include "sac_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1715,6 +1716,8 @@ int td3_trainer_create(sac_trainer_t **out, const td3_config_t *c) {
     return trainer_create(out, &s, c);
 }
 
+static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_config_t *td3);
+
 static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td3_config_t *td3) {
     *out = nullptr;
     SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
@@ -1725,6 +1728,15 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     SAC_REQUIRE(cfg->target_update_period > 0, "target_update_period must be positive");
     SAC_HIP(hipSetDevice(cfg->device));
     sac_trainer *t = new sac_trainer();
+    if (trainer_build(t, cfg, td3)) {        // (the error message is already set)
+        sac_trainer_destroy(t);
+        return -1;
+    }
+    *out = t;
+    return 0;
+}
+
+static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_config_t *td3) {
     t->cfg = *cfg; t->device = cfg->device;
     t->B = cfg->batch; t->O = cfg->obs_dim; t->A = cfg->act_dim;
     t->algo = td3 ? 1 : 0;
@@ -1734,6 +1746,10 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     // column split: small batches spread every 256-wide layer over 4 workgroups per row-block; once the
     // row-blocks alone fill the 256 CUs (B >= 512) fewer, fatter workgroups win.  SP*NB stays even (XCD map).
     t->SP = (t->NB <= 16) ? 4 : (t->NB <= 32 ? 2 : ((t->NB & 1) ? 2 : 1));
+    if (const char *e = getenv("SAC_FORCE_SP")) {       // tuning experiments only
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4) && ((v * t->NB) % 2 == 0)) t->SP = v;
+    }
     SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1893,20 +1909,19 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     }
     SAC_REQUIRE(t->lds_fb <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
     SAC_HIP(hipStreamSynchronize(s));
-    *out = t;
     return 0;
 }
 
 int sac_trainer_destroy(sac_trainer_t *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->device);
-    (void)hipStreamSynchronize(t->stream);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->arena);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_done) if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(t->stream);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return 0;
 }

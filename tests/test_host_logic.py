@@ -61,7 +61,11 @@ def test_default_variant_matches_argparse_defaults_and_dims_table():
     with pytest.raises(KeyError):
         variant.env_dims(dict(env_name="Foo", robots=["Panda"]))
     with pytest.raises(ValueError):
-        variant.validate(dict(v, algorithm="TD3"))
+        variant.validate(dict(v, algorithm="DDPG"))
+    td3 = variant.validate(variant.default_variant(agent="TD3"))     # scripts/train.py:38-47, arguments.py:141-156
+    assert td3["algorithm"] == "TD3" and td3["trainer_kwargs"] == dict(
+        target_policy_noise=0.2, discount=0.99, reward_scale=1.0, policy_learning_rate=1e-3, qf_learning_rate=5e-4,
+        policy_and_target_update_period=2, tau=0.005)
 
 
 def test_path_collection_matches_the_shipped_epoch0_counts():
