@@ -354,15 +354,25 @@ __device__ __forceinline__ void gemm_straight(WRing<NT, D> &R, const float *X, i
 // those loads would only keep the wave stalled at issue (the CU's fill path is the bottleneck) in front of this GEMM.
 template <int NT, int D, int NT1, int D1>
 __device__ __forceinline__ void gemm_straight_pf(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
-                                                 WRing<NT1, D1> &R1, int KS1) {
+                                                 WRing<NT1, D1> &R1, int KS1, int pre = D) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
     constexpr int Q1 = (D1 + 3) / 4;
+    // chunks [0, pre) of this layer were requested before the call; chunk u + pre is requested in front of chunk
+    // u's MFMAs (which run in the background while the wave waits at the next request), then the next layer's ring
 #pragma unroll
     for (int u = 0; u < D; ++u) {
+        if (u + pre < D) {
+            SB();
+            R.fill_part(KS, u + pre, u + pre + 1);
+            SB();
+        }
         if (u < KS) {
             const f32x4 a = ld4(xrow + 4 * ((4 * u + g) ^ r));
+#ifdef SAC_STAMPS
+            if (u < 4) { float probe = R.b[u][NT - 1][3]; asm volatile("" ::"v"(probe)); STAMP(0, 5 + u); }   // chunk u has arrived
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -569,7 +579,11 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, is_pi ? 0 : A, A, d.KP);
     WRing<4, WIDE ? RD : RD0> r0;
     r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
-    r0.fill(K0 >> 4);
+    // narrow first layers: two chunks now, the rest inside the first GEMM (a wave stalled at issue cannot commit the
+    // rows or start its MFMAs; the requests pace themselves at the CU's fill rate either way)
+    constexpr int PRE0 = 2;
+    if constexpr (WIDE) r0.fill(K0 >> 4);
+    else r0.fill_part(K0 >> 4, 0, PRE0);
     float bv0[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
@@ -601,8 +615,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         f32x4 acc[4] = {};
         if constexpr (WIDE) gemm_ring(r0, X0, KL0, K0 >> 4, acc);
         else {
-            gemm_straight_pf(r0, X0, KL0, K0 >> 4, acc, r1, H >> 4);
-            FWD_A_LATE_REQUESTS();
+            gemm_straight_pf(r0, X0, KL0, K0 >> 4, acc, r1, H >> 4, PRE0);
         }
         // Q blocks keep this quarter's PRE-activation z = W1 [s, a] + b for launch B: the first layer is linear in
         // the action, so Q_i(s, a_new) only needs z + W1[:, action chunk] (a_new - a) there instead of streaming
@@ -615,6 +628,9 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
     }
     lds_barrier();
     STAMP(0, 2);
+    // (the slice's bias and the head weights are only needed behind the slice GEMM: requested behind the barrier, where
+    //  a wave stalled at issue holds nobody up)
+    if constexpr (!WIDE) FWD_A_LATE_REQUESTS();
     {   // this block's columns of the 256x256 layer
         f32x4 acc[NTW] = {};
         gemm_ring(r1, X1, H, H >> 4, acc);
