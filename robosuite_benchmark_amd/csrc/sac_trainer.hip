@@ -1,8 +1,10 @@
-// SAC gradient step on MI355X (gfx950): four row-block / tile-owner kernels per step.
+// SAC (and TD3) gradient step on MI355X (gfx950): four row-block / tile-owner kernels per step.
 //
 // Replaces rlkit SACTrainer.train_from_torch (+ np_to_pytorch_batch, soft_update_from_to); call
 // sites /root/reference/util/rlkit_utils.py:64-106, /root/reference/util/rlkit_custom.py:238.
 // Normative step order: SURVEY.md Appendix A (lines 1-18), ordering O1, logging quirk Q1.
+// TD3 (rlkit TD3Trainer, /root/reference/util/rlkit_utils.py:107-135) runs on the same kernels as compile-time
+// variants (MODE = M_TD3_CRITIC / M_TD3_ACTOR, see launch_step_td3).
 //
 // Decomposition (DESIGN.md "Kernels"): batch rows are independent through forward and backward-dX,
 // so a workgroup owns a 16-row block (one MFMA 16x16x4 M-tile) and chains whole layers through LDS;
@@ -11,18 +13,18 @@
 // grid barrier on 8 XCDs); the weight-gradient kernel is tile-owner parallel and applies Adam and
 // the Polyak update in its epilogue, so gradients never round-trip through HBM.
 //
-//   A k_fwd_a       16*B/16 WGs   pi(s), pi(s') -> head partials; Q1,Q2(s,a) -> q partials
-//   B k_fwd_b       16*B/16 WGs   tanh-Gaussian head; Q1,Q2(s,a_new), T1,T2(s',a') -> q partials;
-//                                 Q1,Q2(s,a_new) blocks continue to the UNIT gradient dQ/da (partials)
+//   A k_fwd_a       16*B/16 WGs   pi(s), pi(s') -> head partials; Q1,Q2(s,a) -> q partials (+ first-layer pre-activations z)
+//   B k_fwd_b       16*B/16 WGs   tanh-Gaussian head; Q1,Q2(s,a_new) (first layer = z + W_a (a_new - a)), T1,T2(s',a')
+//                                 -> q partials; the Q(s,a_new) blocks continue to the UNIT gradient dQ/da (partials)
 //   C k_bwd         12*B/16 WGs   critic dL/dh (2 nets) | policy: min-select, head gradient (reparameterised), dL/dh
 //   D k_dw_adam     ~250  WGs     dW = dY^T X over the batch (MFMA), Adam, Polyak, diagnostics
 // (every 256-wide layer is split over 4 workgroups per 16-row block; partial sums meet at launch boundaries)
 //
-// Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round
-// trips, not by FLOPs): the minibatch slot and the step index are launch arguments (no dependent
-// load in front of the first data access); everything a kernel will need later -- ReLU masks,
-// the first D k-chunks of the NEXT layer's weights, device-side scalars -- is loaded at kernel
-// entry into registers, so one L2/Infinity-Cache round trip is paid per kernel, not per layer.
+// Latency rules every kernel follows (a step is ~0.6 GFLOP: it is bound by dependent memory round trips and by
+// the ~20 B/clk a CU's fill path sustains, not by FLOPs) -- DESIGN.md section 4 has the list with the measurements:
+// launch arguments instead of device counters, kernel arguments prefetched into the scalar cache, requests in
+// consumption order and paced between independent work, register-ring weight stream, LDS-only barriers,
+// unconditional loads, global stores behind the last load request, compile-time variants inside GEMM loops.
 #include "sac_common.h"
 
 #include <cmath>
@@ -250,9 +252,6 @@ struct WRing {
 // `stage` != null: every weight fragment is also copied to LDS as it leaves the ring, TRANSPOSED: stage[k][row of W]
 // with row stride WLD (this wave's tile t owns columns 16 t ..), for a later contraction over the rows of W
 // (gemm_lds_rows) -- the same bytes a backward pass would otherwise fetch again from the transposed copy.
-#ifndef SAC_STAGE
-#define SAC_STAGE 1
-#endif
 constexpr int WLD = 64 + 4;       // 64 staged weight rows; +4: scatter writes and 16-B reads are bank-conflict free
 template <bool STAGED = false, int NT, int D>
 __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
@@ -279,24 +278,17 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
 #pragma unroll
                         for (int i = 0; i < 4; ++i) stage[(16 * S + 4 * g + i) * WLD + 16 * t + r] = bc[t][i];
                 }
-#ifndef SAC_ABLATE_LOADS
                 if (S + D < KS) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 16 * (S + D));
                 }
-#endif
                 SB();
-#ifndef SAC_ABLATE_MFMA
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], bc[t][i], acc[t], 0, 0, 0);
                 }
-#else
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { asm volatile("" :: "v"(bc[t])); acc[t] += bc[t] * a_cur; }
-#endif
                 SB();
                 a_cur = a_nxt;
             }
@@ -675,7 +667,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     float *X1 = XQ + RB * KLQ;           // [16][256]
     float *XS = X1 + RB * H;             // [16][SW]
     float *red = XS + RB * SW;           // 1024 floats (split-K scratch of the actor tail)
-    constexpr bool STAGE = (SP == 4) && SAC_STAGE;    // 64-row weight slice (66.5 KB) fits LDS: the actor tail reads it from there
+    constexpr bool STAGE = (SP == 4);    // 64-row weight slice (68 KB transposed) fits LDS: the actor tail reads it from there
     float *WL = red + 1024;              // [256][WLD]  (STAGE only)
     // XCD-aware map (see k_fwd_a): b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> T1, {6,7} -> T2
     const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
