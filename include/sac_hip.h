@@ -116,7 +116,8 @@ int sac_read_slot(sac_buffer_t *buf, int64_t slot, float *obs, float *act, float
 typedef struct sac_config {
     int32_t obs_dim, act_dim;
     int32_t hidden;              /* both hidden layers; 256 in every shipped variant.json */
-    int32_t batch;               /* algorithm_kwargs.batch_size */
+    int32_t batch;               /* algorithm_kwargs.batch_size: any positive size (slots are padded to whole 16-row
+                                  * blocks; pad rows carry zero weight in every mean of the step) */
     float discount;              /* trainer_kwargs.discount */
     float reward_scale;          /* trainer_kwargs.reward_scale */
     float policy_lr, qf_lr;      /* trainer_kwargs.policy_lr / qf_lr (alpha uses policy_lr) */

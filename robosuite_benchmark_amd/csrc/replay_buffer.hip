@@ -28,8 +28,10 @@ const char *last_error() { return g_err.c_str(); }
 // accepted draws are compacted in draw order with a ballot prefix, so output j is exactly the j-th
 // accepted draw and the stream stops right after the draw that produced the last output.
 // ------------------------------------------------------------------------------------------
+// Output j goes to out[(j / bt) * bp + j % bt]: batches of bt indices stored at a stride of bp >= bt (the row-block
+// padding of a batch whose size is not a multiple of 16; the pad entries keep a valid index and are never drawn).
 __global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, uint32_t mask, int64_t count,
-                                                   int64_t *__restrict__ out) {
+                                                   int64_t *__restrict__ out, int bt, int bp) {
     __shared__ uint32_t mt[MT_N];
     __shared__ int s_newpos;
     const int lane = threadIdx.x;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, ui
             const int before = __popcll(bal & ((1ull << lane) - 1ull));
             const int total = __popcll(bal);
             const int64_t slot = produced + before;
-            if (ok && slot < count) out[slot] = (int64_t)v;
+            if (ok && slot < count) out[(bt == bp) ? slot : (slot / bt) * bp + slot % bt] = (int64_t)v;
             if (produced + total >= count) {
                 if (ok && slot == count - 1) s_newpos = i + 1;
                 __syncthreads();
@@ -293,6 +295,7 @@ int ensure_idx(sac_buffer *b, int64_t n) {
     b->d_idx = nullptr;
     b->idx_cap = 0;
     SAC_HIP(hipMalloc(&b->d_idx, sizeof(int64_t) * n));
+    SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * n, b->stream));      // pad entries: a valid index
     b->idx_cap = n;
     return 0;
 }
@@ -308,7 +311,7 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
         // padding rows of saT (between and after obs / act) are contracted by the weight-gradient kernel: keep them 0
         SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
         b->slots_cap = need;
-    } else if (b->slot.B != B) {
+    } else if (b->slot.Bt != B) {
         SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
     }
     b->slot = L;
@@ -316,24 +319,26 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
     return 0;
 }
 
-// dst == null: into b->d_idx + idx_offset (grown as needed when idx_offset == 0)
+// `batch` indices per batch, stored at a stride of round_up(batch, 16).  dst == null: into b->d_idx + idx_offset
+// (idx_offset in elements of that padded layout; the buffer is grown as needed when idx_offset == 0).
 int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst) {
-    const int64_t count = (int64_t)batch * n_batches;
+    const int bp = round_up(batch, RB);
+    const int64_t count = (int64_t)batch * n_batches, padded = (int64_t)bp * n_batches;
     SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
     SAC_REQUIRE(b->size - 1 <= 0xffffffffLL, "replay buffers above 2^32 slots are not supported");
     if (!dst) {
-        if (idx_offset == 0 && ensure_idx(b, count)) return -1;
-        SAC_REQUIRE(idx_offset + count <= b->idx_cap, "index buffer too small for this offset");
+        if (idx_offset == 0 && ensure_idx(b, padded)) return -1;
+        SAC_REQUIRE(idx_offset + padded <= b->idx_cap, "index buffer too small for this offset");
         dst = b->d_idx + idx_offset;
     }
     const uint32_t rng = (uint32_t)(b->size - 1);
     if (rng == 0) {     // NumPy: no draws consumed, all zeros
-        SAC_HIP(hipMemsetAsync(dst, 0, sizeof(int64_t) * count, b->stream));
+        SAC_HIP(hipMemsetAsync(dst, 0, sizeof(int64_t) * padded, b->stream));
         return 0;
     }
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, dst);
+    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, dst, batch, bp);
     SAC_HIP(hipGetLastError());
     return 0;
 }
@@ -570,10 +575,9 @@ int sac_sample_indices(sac_buffer_t *b, int batch, int64_t n_batches, int64_t *i
     SAC_REQUIRE(b && batch > 0 && n_batches > 0, "bad arguments to sac_sample_indices");
     SAC_HIP(hipSetDevice(b->device));
     if (launch_sample(b, batch, n_batches)) return -1;
-    if (idx_out) {
-        SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch * n_batches, hipMemcpyDeviceToHost,
-                               b->stream));
-    }
+    if (idx_out)        // (device layout: stride round_up(batch, 16) per batch)
+        SAC_HIP(hipMemcpy2DAsync(idx_out, sizeof(int64_t) * batch, b->d_idx, sizeof(int64_t) * round_up(batch, RB),
+                                 sizeof(int64_t) * batch, (size_t)n_batches, hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -582,7 +586,7 @@ static int copy_slot_out(sac_buffer *b, int64_t slot, float *obs, float *act, fl
                          float *nobs) {
     const SlotLayout &L = b->slot;
     const float *S = b->d_slots + slot * L.slot_floats;
-    const int B = L.B;
+    const int B = L.Bt;                 // the rows that were asked for (the slot may hold row-block padding behind them)
     if (obs) SAC_HIP(hipMemcpyAsync(obs, S + L.off_obs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, b->stream));
     if (act) SAC_HIP(hipMemcpyAsync(act, S + L.off_act, sizeof(float) * B * L.A, hipMemcpyDeviceToHost, b->stream));
     if (rew) SAC_HIP(hipMemcpyAsync(rew, S + L.off_rew, sizeof(float) * B, hipMemcpyDeviceToHost, b->stream));
@@ -597,7 +601,7 @@ int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *
     SAC_HIP(hipSetDevice(b->device));
     if (launch_sample(b, batch, 1)) return -1;
     if (ensure_slots(b, batch, 1)) return -1;
-    if (launch_gather(b, b->d_idx, batch, 1, b->d_slots, b->slot, 1)) return -1;
+    if (launch_gather(b, b->d_idx, b->slot.B, 1, b->d_slots, b->slot, 1)) return -1;
     if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
     if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
@@ -606,14 +610,15 @@ int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *
 
 // ---- device-resident batches (the stepwise interface without a PCIe round trip per step) ----------------
 static int ensure_ring(sac_buffer *b, int batch) {
-    if (b->d_ring && b->ring_layout.B == batch) return 0;
+    if (b->d_ring && b->ring_layout.Bt == batch) return 0;
     SAC_HIP(hipStreamSynchronize(b->stream));
     if (b->d_ring) { SAC_HIP(hipFree(b->d_ring)); SAC_HIP(hipFree(b->d_ring_idx)); b->d_ring = nullptr; b->d_ring_idx = nullptr; }
     b->ring_layout = make_slot_layout(batch, b->O, b->A);
     const size_t nfl = (size_t)b->ring_layout.slot_floats * sac_buffer::NRING;
     SAC_HIP(hipMalloc(&b->d_ring, sizeof(float) * nfl));
     SAC_HIP(hipMemsetAsync(b->d_ring, 0, sizeof(float) * nfl, b->stream));    // saT padding rows stay 0
-    SAC_HIP(hipMalloc(&b->d_ring_idx, sizeof(int64_t) * (size_t)batch * sac_buffer::NRING));
+    SAC_HIP(hipMalloc(&b->d_ring_idx, sizeof(int64_t) * (size_t)b->ring_layout.B * sac_buffer::NRING));
+    SAC_HIP(hipMemsetAsync(b->d_ring_idx, 0, sizeof(int64_t) * (size_t)b->ring_layout.B * sac_buffer::NRING, b->stream));
     for (int i = 0; i < sac_buffer::NRING; ++i) {
         b->ring_token[i] = -1; b->ring_in_use[i] = false;
         if (!b->ring_ready[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_ready[i], hipEventDisableTiming));
@@ -630,9 +635,9 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     const int slot = (int)(n % sac_buffer::NRING);
     // the slot's previous batch may still be read by a step in flight on a trainer's stream
     if (b->ring_in_use[slot]) { SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0)); b->ring_in_use[slot] = false; }
-    int64_t *didx = b->d_ring_idx + (size_t)slot * batch;
+    int64_t *didx = b->d_ring_idx + (size_t)slot * b->ring_layout.B;
     if (launch_sample(b, batch, 1, 0, didx)) return -1;
-    if (launch_gather(b, didx, batch, 1, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;
+    if (launch_gather(b, didx, b->ring_layout.B, 1, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;
     SAC_HIP(hipEventRecord(b->ring_ready[slot], b->stream));
     b->ring_token[slot] = n;
     b->ring_next = n + 1;
@@ -659,14 +664,14 @@ int sac_read_batch_device(sac_buffer_t *b, int64_t token, float *obs, float *act
     SAC_HIP(hipSetDevice(b->device));
     const SlotLayout &L = b->ring_layout;
     const float *S = b->d_ring + (size_t)slot * L.slot_floats;
-    const int B = L.B;
+    const int B = L.Bt;
     hipStream_t s = b->stream;          // in order behind the gather that filled the slot
     if (obs) SAC_HIP(hipMemcpyAsync(obs, S + L.off_obs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, s));
     if (act) SAC_HIP(hipMemcpyAsync(act, S + L.off_act, sizeof(float) * B * L.A, hipMemcpyDeviceToHost, s));
     if (rew) SAC_HIP(hipMemcpyAsync(rew, S + L.off_rew, sizeof(float) * B, hipMemcpyDeviceToHost, s));
     if (term) SAC_HIP(hipMemcpyAsync(term, S + L.off_term, sizeof(float) * B, hipMemcpyDeviceToHost, s));
     if (next_obs) SAC_HIP(hipMemcpyAsync(next_obs, S + L.off_nobs, sizeof(float) * B * L.O, hipMemcpyDeviceToHost, s));
-    if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_ring_idx + (size_t)slot * B, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s));
+    if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_ring_idx + (size_t)slot * L.B, sizeof(int64_t) * B, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
     return 0;
 }
@@ -678,10 +683,11 @@ int sac_gather(sac_buffer_t *b, const int64_t *idx, int batch, float *obs, float
     for (int i = 0; i < batch; ++i)
         SAC_REQUIRE(idx[i] >= 0 && idx[i] < b->size, "index %lld out of range [0, %lld)", (long long)idx[i],
                     (long long)b->size);
-    if (ensure_idx(b, batch)) return -1;
     if (ensure_slots(b, batch, 1)) return -1;
+    if (ensure_idx(b, b->slot.B)) return -1;
+    SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * b->slot.B, b->stream));
     SAC_HIP(hipMemcpyAsync(b->d_idx, idx, sizeof(int64_t) * batch, hipMemcpyHostToDevice, b->stream));
-    if (launch_gather(b, b->d_idx, batch, 1, b->d_slots, b->slot, 1)) return -1;
+    if (launch_gather(b, b->d_idx, b->slot.B, 1, b->d_slots, b->slot, 1)) return -1;
     if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
     SAC_HIP(hipStreamSynchronize(b->stream));
     return 0;
@@ -694,7 +700,7 @@ int sac_sample_gather_device(sac_buffer_t *b, int batch, int64_t n_batches, floa
     SAC_HIP(hipEventRecord(b->ev[0], b->stream));
     if (launch_sample(b, batch, n_batches)) return -1;
     SAC_HIP(hipEventRecord(b->ev[1], b->stream));
-    if (launch_gather(b, b->d_idx, batch, n_batches, b->d_slots, b->slot, 1)) return -1;
+    if (launch_gather(b, b->d_idx, b->slot.B, n_batches, b->d_slots, b->slot, 1)) return -1;
     SAC_HIP(hipEventRecord(b->ev[2], b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
     if (kernel_ms) {
@@ -710,7 +716,7 @@ int sac_read_slot(sac_buffer_t *b, int64_t slot, float *obs, float *act, float *
     SAC_HIP(hipSetDevice(b->device));
     if (copy_slot_out(b, slot, obs, act, rew, term, next_obs)) return -1;
     if (idx_out)
-        SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx + slot * b->slot.B, sizeof(int64_t) * b->slot.B,
+        SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx + slot * b->slot.B, sizeof(int64_t) * b->slot.Bt,
                                hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
     return 0;

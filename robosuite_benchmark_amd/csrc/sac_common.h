@@ -42,7 +42,9 @@ static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m 
 // out [obs | 0-pad to KA | act | 0-pad to KQ] with KA = round_up(O, 16): the action sits in a k-chunk (16 columns)
 // of its own, so a first-layer GEMM can be split into its observation part and its action part.
 struct SlotLayout {
-    int B, O, A;
+    int B, O, A;                  // B: rows of the slot = the batch size rounded up to a multiple of 16 (row-blocks)
+    int Bt;                       // rows that hold a sampled transition (the batch size asked for); the rest is padding
+                                  // (it repeats buffer row 0 and carries zero weight in every mean of the step)
     int KA;                       // first action row of saT / action column of the Q-net input: round_up(O, 16)
     int KQ;                       // KA + 16
     int KQ64;                     // rows allocated for saT: round_up(KQ, 64) (64-wide k strips)
@@ -50,9 +52,10 @@ struct SlotLayout {
     int64_t slot_floats;          // multiple of 64 floats (256 B)
 };
 
-static inline SlotLayout make_slot_layout(int B, int O, int A) {
+static inline SlotLayout make_slot_layout(int batch, int O, int A) {
     SlotLayout L;
-    L.B = B; L.O = O; L.A = A;
+    const int B = round_up(batch, RB);
+    L.B = B; L.Bt = batch; L.O = O; L.A = A;
     L.KA = round_up(O, 16);
     L.KQ = L.KA + 16;
     L.KQ64 = round_up(L.KQ, 64);

@@ -78,7 +78,8 @@ struct Net {
 
 // everything the step kernels need, passed by value
 struct Dev {
-    int B, O, A, KP, KQ, NH, NB;   // KP = pad16(O), KQ = KP + 16 (Q input: [obs | pad | act | pad]), NH = pad16(2A), NB = B/16
+    int B, Bt;                     // batch rows padded to a multiple of 16 / rows that count (the rest has zero weight)
+    int O, A, KP, KQ, NH, NB;      // KP = pad16(O), KQ = KP + 16 (Q input: [obs | pad | act | pad]), NH = pad16(2A), NB = B/16
     float discount, reward_scale, tau, target_entropy, alpha_lr;
     int period, auto_alpha;
     unsigned long long noise_seed;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
     SB();
     const float lsum = group16_sum(lp);
-    if (own_s && a == 0) red[row] = lsum;
+    if (own_s && a == 0) red[row] = (grow < d.Bt) ? lsum : 0.f;          // (pad rows carry no weight)
     lds_barrier();
     float lsum_blk = 0.f;
     if (own_s && threadIdx.x == 0) {          // this row-block's sum(log_pi), fixed order
@@ -925,7 +926,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const float *P = d.P[1 + qi];
     const float *PT = d.PT[1 + qi];
-    const float invB = 1.0f / (float)B;
+    const float invB = 1.0f / (float)d.Bt;                   // means run over the true batch; pad rows get dq = 0
     const float *h2T = d.QH2T + (size_t)qi * H * B;
     const float *h1T = d.QH1T + (size_t)qi * H * B;
     const int n0 = SW * part + 16 * NTW * wave;
@@ -964,7 +965,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
     float alpha = 0.f;                                                   // (TD3: no entropy term in the target)
     if constexpr (MODE == M_SAC)
-        alpha = alpha_step(d.ctl, d.part_logpi, NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        alpha = alpha_step(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
 #pragma unroll
     for (int p = 0; p < SP; ++p) { USE_FROM_HERE(qa[p]); USE_FROM_HERE(qb[p]); USE_FROM_HERE(qq[p]); }
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
@@ -978,7 +979,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
         vq += b3q;                                                       // Q_i(s,a)
         const float tq = fminf(va, vb) - alpha * in_c;
         yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
-        dq = 2.0f * (vq - yv) * invB;
+        dq = (row0 + (int)threadIdx.x < d.Bt) ? 2.0f * (vq - yv) * invB : 0.f;
         s_dq[threadIdx.x] = dq;
     }
     lds_barrier();
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const float *PT = d.PT[0];
-    const float invB = 1.0f / (float)B;
+    const float invB = 1.0f / (float)d.Bt;                   // means run over the true batch; pad rows get no gradient
     const int n0 = SW * part + 16 * NTW * wave;
     const long long oB3 = d.LQ[2].offB;
 
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
     float alpha = 0.f;
     if constexpr (MODE == M_SAC)
-        alpha = alpha_step(d.ctl, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        alpha = alpha_step(d.ctl, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     lds_barrier();
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
 #pragma unroll
@@ -1093,7 +1094,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
         const float sel1 = (MODE == M_SAC) ? ((va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f)) : 1.0f;   // TD3: Q1 only
         const float dq1 = -invB * sel1, dq2 = -invB * (1.0f - sel1);
         qnew1 = va; qnew2 = vb;
-        if (a < A) {
+        if (a < A && row0 + row < d.Bt) {
             float da1 = dap[0], da2 = dap[SP];
 #pragma unroll
             for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
@@ -1194,7 +1195,8 @@ constexpr int NSTAT = 6;     // q1, q2, q_target, log_pi, mu, log_std
 // sa.pad bit 0: the critic part (every step, from the critic launch), bit 1: the policy part (policy / statistics
 // steps, from the launch that follows the actor pass).
 __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa, float *red) {
-    const int B = d.B, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, loop_pos = sa.loop_pos;
+    const int B = d.Bt, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, loop_pos = sa.loop_pos;   // statistics over the true batch
+    const size_t Bs = (size_t)d.B;                           // (row stride of the per-row arrays: the padded batch)
     constexpr int NS = 6;        // q1, q2, y, be1, be2, policy action
     double sm[NS], sq[NS], lsum = 0;
     float mx[NS], mn[NS];
@@ -1203,16 +1205,16 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
     auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
     if (sa.pad & 1)
         for (int i = threadIdx.x; i < B; i += 256) {
-            const float yv = d.y[i], q1 = d.q[i], q2 = d.q[(size_t)B + i];
+            const float yv = d.y[i], q1 = d.q[i], q2 = d.q[Bs + i];
             acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, (q1 - yv) * (q1 - yv)); acc1(4, (q2 - yv) * (q2 - yv));
         }
     if (sa.pad & 2) {
         const float b3 = sload(d.P[1] + d.LQ[2].offB);
         for (int i = threadIdx.x; i < B; i += 256) {                                             // Q1(s, policy(s))
-            float qv = d.qpart[((size_t)2 * d.sp) * B + i];
-            for (int p = 1; p < d.sp; ++p) qv += d.qpart[((size_t)2 * d.sp + p) * B + i];       // fixed order
+            float qv = d.qpart[((size_t)2 * d.sp) * Bs + i];
+            for (int p = 1; p < d.sp; ++p) qv += d.qpart[((size_t)2 * d.sp + p) * Bs + i];       // fixed order
             lsum += (double)(qv + b3);
-            d.q[2 * (size_t)B + i] = qv + b3;
+            d.q[2 * Bs + i] = qv + b3;
         }
         for (int e = threadIdx.x; e < B * d.A; e += 256) { const int i = e / d.A; acc1(5, d.anew[i * 16 + (e - i * d.A)]); }
     }
@@ -1411,9 +1413,10 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         td3_diagnostics(d, sa, red);
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
-        const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, B, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
+        const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
         const float alpha = as.alpha, alpha_loss = as.alpha_loss;
         const int loop_pos = sa.loop_pos;
+        const int Bt = d.Bt;                 // statistics and losses run over the true batch (B is the padded row stride)
         double sm[NSTAT], sq[NSTAT], ls4[4];
         float mx[NSTAT], mn[NSTAT];
 #pragma unroll
@@ -1421,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
         for (int q = 0; q < 4; ++q) ls4[q] = 0;
         auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
-        for (int i = threadIdx.x; i < B; i += 256) {
+        for (int i = threadIdx.x; i < Bt; i += 256) {
             const float yv = d.y[i], q1 = d.q[i], q2 = d.q[(size_t)B + i], lp = d.logpi[i];
             const float e1 = q1 - yv, e2 = q2 - yv;
             const float qn = fminf(d.q[2 * (size_t)B + i], d.q[3 * (size_t)B + i]);
@@ -1429,7 +1432,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             ls4[2] += (double)(lp - qn); ls4[3] += (double)(alpha * lp - qn);
             acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, lp);
         }
-        for (int e = threadIdx.x; e < B * d.A; e += 256) {
+        for (int e = threadIdx.x; e < Bt * d.A; e += 256) {
             const int i = e / d.A, jj = e - i * d.A;
             acc1(4, d.mu[i * 16 + jj]); acc1(5, d.ls[i * 16 + jj]);
         }
@@ -1461,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
                 s += sh[w * 32 + q]; s2 += sh[w * 32 + 6 + q];
                 MX = fmax(MX, sh[w * 32 + 12 + q]); MN = fmin(MN, sh[w * 32 + 18 + q]);
             }
-            const double cnt = (q < 4) ? (double)B : (double)B * d.A;
+            const double cnt = (q < 4) ? (double)Bt : (double)Bt * d.A;
             const double mean = s / cnt;
             double var = s2 / cnt - mean * mean;
             if (var < 0) var = 0;
@@ -1479,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (q < 4) {
                 double s = 0;
                 for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24 + q];
-                v = (float)(s / B);
+                v = (float)(s / Bt);
             } else if (q == 4) {
                 v = alpha; di = SAC_D_ALPHA;
                 Ctl *cw = d.ctl;                   // the step's only writer of the entropy-coefficient state
@@ -1506,7 +1509,7 @@ struct sac_trainer {
     sac_config_t cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    int B = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0, SP = 4;
+    int B = 0, Bt = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0, SP = 4;   // B: batch padded to row-blocks, Bt: true batch
     Net net[6];                                       // 5: TD3 target policy
     int algo = 0;                                     // 0 SAC, 1 TD3
     int td3_period = 2;                               // policy_and_target_update_period
@@ -1688,9 +1691,9 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
 
 // sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
 int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
-    if (ensure_slots(b, t->B, n_steps)) return -1;
+    if (ensure_slots(b, t->Bt, n_steps)) return -1;
     SAC_HIP(hipEventRecord(b->ev[0], b->stream));
-    if (launch_sample(b, t->B, n_steps)) return -1;
+    if (launch_sample(b, t->Bt, n_steps)) return -1;
     SAC_HIP(hipEventRecord(b->ev[1], b->stream));
     if (launch_gather(b, b->d_idx, t->B, n_steps, b->d_slots, b->slot, 1)) return -1;
     SAC_HIP(hipEventRecord(b->ev[2], b->stream));
@@ -1732,7 +1735,7 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     SAC_REQUIRE(cfg->hidden == H, "hidden size %d unsupported (only 256, as in every shipped variant.json)", cfg->hidden);
     SAC_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16,
                 "unsupported dims obs=%d act=%d (act_dim must be in 1..16)", cfg->obs_dim, cfg->act_dim);
-    SAC_REQUIRE(cfg->batch > 0 && cfg->batch % 16 == 0, "batch size %d must be a positive multiple of 16", cfg->batch);
+    SAC_REQUIRE(cfg->batch > 0, "batch size %d must be positive", cfg->batch);
     SAC_REQUIRE(cfg->target_update_period > 0, "target_update_period must be positive");
     SAC_HIP(hipSetDevice(cfg->device));
     sac_trainer *t = new sac_trainer();
@@ -1746,7 +1749,7 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
 
 static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_config_t *td3) {
     t->cfg = *cfg; t->device = cfg->device;
-    t->B = cfg->batch; t->O = cfg->obs_dim; t->A = cfg->act_dim;
+    t->Bt = cfg->batch; t->B = round_up(cfg->batch, RB); t->O = cfg->obs_dim; t->A = cfg->act_dim;
     t->algo = td3 ? 1 : 0;
     if (td3) t->td3_period = td3->policy_and_target_update_period;
     t->KP = round_up(t->O, 16); t->KQ = t->KP + 16; t->NH = round_up((td3 ? 1 : 2) * t->A, 16);
@@ -1793,7 +1796,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     for (auto &p : parts) tot += round_up64(p.second, 64);
     if (alloc_zero(&t->ws, tot, s)) return -1;
     t->ws_floats = tot;
-    t->ext_layout = make_slot_layout(B, t->O, t->A);
+    t->ext_layout = make_slot_layout(t->Bt, t->O, t->A);
     if (alloc_zero(&t->ext_slot, t->ext_layout.slot_floats, s)) return -1;
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
@@ -1804,7 +1807,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     tot = 0;
     for (auto &p : parts) { *p.first = t->ws + tot; tot += round_up64(p.second, 64); }
 
-    d.B = B; d.O = t->O; d.A = t->A; d.KP = t->KP; d.KQ = t->KQ; d.NH = t->NH; d.NB = t->NB;
+    d.B = B; d.Bt = t->Bt; d.O = t->O; d.A = t->A; d.KP = t->KP; d.KQ = t->KQ; d.NH = t->NH; d.NB = t->NB;
     d.discount = cfg->discount; d.reward_scale = cfg->reward_scale; d.tau = cfg->soft_target_tau;
     d.target_entropy = std::isnan(cfg->target_entropy) ? -(float)t->A : cfg->target_entropy;
     d.alpha_lr = cfg->policy_lr; d.period = cfg->target_update_period;
@@ -2042,20 +2045,21 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     SAC_REQUIRE(t->algo == 1 || (eps1 == nullptr) == (eps2 == nullptr), "eps1 and eps2 must both be given or both be NULL");
     if (t->algo == 1) eps1 = eps2;                       // TD3 draws one noise tensor (target smoothing): eps2
     SAC_HIP(hipSetDevice(t->device));
-    const int B = t->B, O = t->O, A = t->A;
+    const int B = t->B, Bt = t->Bt, O = t->O, A = t->A;     // B: slot rows (padded to row-blocks), Bt: rows given
     const SlotLayout &L = t->ext_layout;
     hipStream_t s = t->stream;
-    // np_to_pytorch_batch: host fp32 -> pinned -> HBM slot (row-major part), + feature-major saT
+    // np_to_pytorch_batch: host fp32 -> pinned -> HBM slot (row-major part), + feature-major saT; rows beyond the
+    // batch (row-block padding) are zero and carry no weight
     const size_t nfl = (size_t)B * (2 * O + A + 2) + (size_t)L.KQ64 * B + (eps1 ? 2 * (size_t)B * A : 0);
     if (ensure_stage_t(t, sizeof(float) * nfl)) return -1;
     float *st = (float *)t->h_stage;
+    memset(st, 0, sizeof(float) * nfl);
     float *so = st, *sa = so + (size_t)B * O, *sr = sa + (size_t)B * A, *stt = sr + B, *sn = stt + B,
           *sT = sn + (size_t)B * O, *se = sT + (size_t)L.KQ64 * B;
-    memcpy(so, obs, sizeof(float) * B * O); memcpy(sa, act, sizeof(float) * B * A);
-    memcpy(sr, rew, sizeof(float) * B); memcpy(stt, term, sizeof(float) * B);
-    memcpy(sn, next_obs, sizeof(float) * B * O);
-    memset(sT, 0, sizeof(float) * (size_t)L.KQ64 * B);
-    for (int b = 0; b < B; ++b) {
+    memcpy(so, obs, sizeof(float) * Bt * O); memcpy(sa, act, sizeof(float) * Bt * A);
+    memcpy(sr, rew, sizeof(float) * Bt); memcpy(stt, term, sizeof(float) * Bt);
+    memcpy(sn, next_obs, sizeof(float) * Bt * O);
+    for (int b = 0; b < Bt; ++b) {
         for (int k = 0; k < O; ++k) sT[(size_t)k * B + b] = obs[(size_t)b * O + k];
         for (int k = 0; k < A; ++k) sT[(size_t)(L.KA + k) * B + b] = act[(size_t)b * A + k];
     }
@@ -2067,7 +2071,7 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     SAC_HIP(hipMemcpyAsync(E + L.off_nobs, sn, sizeof(float) * B * O, hipMemcpyHostToDevice, s));
     SAC_HIP(hipMemcpyAsync(E + L.off_saT, sT, sizeof(float) * (size_t)L.KQ64 * B, hipMemcpyHostToDevice, s));
     if (eps1) {
-        memcpy(se, eps1, sizeof(float) * B * A); memcpy(se + (size_t)B * A, eps2, sizeof(float) * B * A);
+        memcpy(se, eps1, sizeof(float) * Bt * A); memcpy(se + (size_t)B * A, eps2, sizeof(float) * Bt * A);
         SAC_HIP(hipMemcpyAsync(t->d_eps, se, sizeof(float) * 2 * B * A, hipMemcpyHostToDevice, s));
         t->dev.eps1 = t->d_eps; t->dev.eps2 = t->d_eps + (size_t)B * A;
     } else {
@@ -2087,7 +2091,7 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
     const int slot = sac_ring_slot_of(b, token);
     if (slot < 0) return -1;
-    SAC_REQUIRE(b->ring_layout.B == t->B, "device batch holds %d rows, the trainer was created for %d", b->ring_layout.B, t->B);
+    SAC_REQUIRE(b->ring_layout.Bt == t->Bt, "device batch holds %d rows, the trainer was created for %d", b->ring_layout.Bt, t->Bt);
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[slot], 0));
@@ -2118,7 +2122,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     const int64_t CH = 256;
     const int64_t n_chunks = (n_steps + CH - 1) / CH;
     const int64_t n_slots = n_steps < 2 * CH ? n_steps : 2 * CH;
-    if (ensure_slots(b, t->B, n_slots)) return -1;
+    if (ensure_slots(b, t->Bt, n_slots)) return -1;
     if (ensure_idx(b, n_slots * t->B)) return -1;
     SAC_HIP(hipEventRecord(t->ev[0], s));
     for (int64_t c = 0; c < n_chunks; ++c) {
@@ -2127,7 +2131,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         const int64_t slot0 = (n_chunks == 1) ? 0 : half * CH;
         if (c >= 2) SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[half], 0));   // trainer is done with this half
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[0], b->stream));
-        if (launch_sample(b, t->B, m, slot0 * t->B)) return -1;
+        if (launch_sample(b, t->Bt, m, slot0 * t->B)) return -1;
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[1], b->stream));
         if (launch_gather(b, b->d_idx + slot0 * t->B, t->B, m, b->d_slots + (size_t)slot0 * b->slot.slot_floats, b->slot, 1))
             return -1;
@@ -2229,10 +2233,11 @@ int64_t sac_debug_fetch(sac_trainer_t *t, const char *name, float *out, int64_t 
     const Row16 r16[] = {{"a_new", d.anew}, {"mu", d.mu}, {"log_std", d.ls}, {"a_next", d.a2}, {"z", d.z}};
     for (auto &e : r16)
         if (nm == e.n) {
-            if (cap < (int64_t)B * A) { sac::set_error("buffer too small"); return -2; }
-            if (fetch(e.p, 16LL * B, h)) return -1;
-            for (int b = 0; b < B; ++b) for (int a = 0; a < A; ++a) out[(size_t)b * A + a] = h[(size_t)b * 16 + a];
-            return (int64_t)B * A;
+            const int Bt = t->Bt;           // (the rows of the true batch)
+            if (cap < (int64_t)Bt * A) { sac::set_error("buffer too small"); return -2; }
+            if (fetch(e.p, 16LL * Bt, h)) return -1;
+            for (int b = 0; b < Bt; ++b) for (int a = 0; a < A; ++a) out[(size_t)b * A + a] = h[(size_t)b * 16 + a];
+            return (int64_t)Bt * A;
         }
     struct Vec { const char *n; const float *p; };
     const Vec vecs[] = {{"log_pi", d.logpi}, {"log_pi_next", d.logpi2}, {"q1", d.q}, {"q2", d.q + B},
@@ -2240,10 +2245,11 @@ int64_t sac_debug_fetch(sac_trainer_t *t, const char *name, float *out, int64_t 
                         {"tq1", d.q + 4 * (size_t)B}, {"tq2", d.q + 5 * (size_t)B}, {"q_target", d.y}};
     for (auto &e : vecs)
         if (nm == e.n) {
-            if (cap < B) { sac::set_error("buffer too small"); return -2; }
-            if (fetch(e.p, B, h)) return -1;
-            memcpy(out, h.data(), sizeof(float) * B);
-            return B;
+            const int Bt = t->Bt;
+            if (cap < Bt) { sac::set_error("buffer too small"); return -2; }
+            if (fetch(e.p, Bt, h)) return -1;
+            memcpy(out, h.data(), sizeof(float) * Bt);
+            return Bt;
         }
     const char *gn[3] = {"g_policy", "g_qf1", "g_qf2"};
     for (int i = 0; i < 3; ++i)

@@ -109,8 +109,10 @@ def test_gather_given_indices_and_ragged_edges():
     assert_batch_equal(got, want)
     with pytest.raises(RuntimeError):
         dev.gather(np.array([1000] * 16, dtype=np.int64))
+    got17 = dev.random_batch(17, lazy=False)         # not a multiple of the 16-row block: padded internally
+    assert got17["observations"].shape == (17, 42) and got17["rewards"].shape == (17, 1)
     with pytest.raises(RuntimeError):
-        dev.random_batch(17)         # not a multiple of the 16-row block
+        dev.random_batch(0)
 
 
 def test_ring_semantics_wraparound_and_size_saturation():
