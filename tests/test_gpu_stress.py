@@ -78,3 +78,24 @@ def test_act_dim_above_sixteen_is_rejected_cleanly():
     qs = [FlattenMlp([256, 256], 1, 37) for _ in range(4)]
     with pytest.raises(RuntimeError, match="act_dim"):
         SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=32)
+
+
+def test_td3_three_thousand_steps_with_an_odd_batch_stay_finite():
+    from robosuite_benchmark_amd._lib import TD3_DIAG_NAMES
+    from tests.helpers import make_td3_pair
+    O, A, B = 46, 7, 200                                   # 200 = 12.5 row-blocks: padded slots all the way
+    _, hip = make_td3_pair(O, A, B, seed=8, noise_seed=5)
+    buf = filled(30_000, O, A, 1)
+    buf.seed(3)
+    first, last = hip.train_loop(buf, 3001, batch_size=B)
+    i = TD3_DIAG_NAMES.index
+    assert np.all(np.isfinite(first[:28])) and np.all(np.isfinite(last[:28]))
+    assert last[i("QF1 Loss")] < first[i("QF1 Loss")]
+    sc = hip.state_dict()["scalars"]
+    assert (sc[0], sc[3], sc[4]) == (1501.0, 3001.0, 3001.0)      # policy steps on even step numbers
+    tmp, rs = np.random.RandomState(0), np.random.RandomState(3)
+    rs.randint(0, 30_000, B * 3001)
+    buf.sync_to_numpy(tmp)
+    assert np.array_equal(tmp.randint(0, 1 << 30, 50), rs.randint(0, 1 << 30, 50))
+    for name in ("policy", "target_policy", "qf1", "target_qf2"):
+        assert np.all(np.isfinite(hip.state_dict()["params"][name]))
