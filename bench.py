@@ -253,6 +253,7 @@ def main():
     ap.add_argument("--task", type=str, default=None,
                     help="N=1 only: another task of the sweep table (e.g. Door, TwoArmHandoff); default Lift")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stepwise", action="store_true", help="skip the extra stepwise-interface data point")
     ap.add_argument("--backend", type=str, default="nccl", help="collective backend for N>1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
@@ -370,7 +371,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(O, A, B)
         elif world == 1:
             out["cpu_baseline"] = None
-        if world == 1:
+        if world == 1 and not args.no_stepwise:
             # the reference's unmodified loop body (random_batch -> train) through the Python duck types, batches
             # staying on the device (DeviceBatch): extra data point, never `value`
             n_sw = min(args.steps, 2000)

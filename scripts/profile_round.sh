@@ -7,7 +7,8 @@ tag=${1:?tag}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.log
+# (the fused loop only: --no-stepwise keeps the stepwise data point, whose steps interleave with per-batch gathers, out of the averages)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline --no-stepwise > $out/bench_under_rocprof.json 2> $out/trace.log
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   set -- $pass
   name=$1; shift
