@@ -1,0 +1,100 @@
+// microbenchmark: what a CU's vector-memory path sustains for the weight-stream access shapes (L2 / Infinity-Cache
+// resident data, one 256-thread workgroup per CU, every CU reading the SAME 128 KB like the step kernels do).
+//   shape 0: lane (c = l&15, g = l>>4) loads 16 B at row c, column 16*S + 4*g   (16 rows x 64 B per wave-instruction)
+//   shape 1: lane l loads 16 B at 1 KB-contiguous chunk S                       (8 full 128-B lines per instruction)
+//   shape 2: like 0 but each CU reads its own 128 KB (no sharing between CUs)
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ unsigned long long g_t[512];
+template <int SHAPE, int INFLIGHT>
+__global__ __launch_bounds__(256) void k(const float *__restrict__ W, float *out, int reps) {
+    if (threadIdx.x == 0) g_t[2 * blockIdx.x] = wall_clock64();
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 15, g = l >> 4;
+    const float *base = W + (SHAPE == 2 ? (size_t)blockIdx.x * 32768 : 0);      // 128 KB per region
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < reps; ++r) {
+        // one pass = this wave's quarter of the region: 32 KB = 32 wave-instructions, INFLIGHT at a time
+        for (int s0 = 0; s0 < 32; s0 += INFLIGHT) {
+            f4 v[INFLIGHT];
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; ++u) {
+                const int S = s0 + u;                 // 0..31
+                const float *p;
+                if (SHAPE == 1) p = base + (size_t)(wave * 32 + S) * 256 + 4 * l;
+                else p = base + (size_t)(wave * 32 + (S >> 4) * 16 + c) * 256 + 16 * (S & 15) + 4 * g;   // 16 rows of 1 KB, chunk S&15
+                v[u] = *reinterpret_cast<const f4 *>(p);
+            }
+#pragma unroll
+            for (int u = 0; u < INFLIGHT; ++u) acc += v[u];
+        }
+    }
+    if (acc[0] == 12345.f) out[threadIdx.x] = acc[1];
+    asm volatile("" ::"v"(acc));
+    __syncthreads();
+    if (threadIdx.x == 0) g_t[2 * blockIdx.x + 1] = wall_clock64();
+}
+template <int SHAPE, int INFLIGHT>
+void run(const float *W, float *out, const char *name) {
+    const int reps = 16;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<SHAPE, INFLIGHT>), dim3(256), dim3(256), 0, 0, W, out, reps);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (it == 2) {
+            const double bytes_per_cu = 128.0 * 1024 * reps;
+            printf("%-34s in flight %2d KB/wave: %6.1f us  %6.1f GB/s per CU  (%.1f B/clk at 2.35 GHz)\n", name, INFLIGHT,
+                   ms * 1e3, bytes_per_cu / (ms * 1e-3) / 1e9, bytes_per_cu / (ms * 1e-3) / 2.35e9);
+        }
+    }
+}
+// cold pass: the region was just rewritten by another kernel (like the weights, every step); ONE pass over it
+__global__ void k_write(float *W, int n, float v) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) W[i] = v + i;
+}
+template <int SHAPE, int INFLIGHT>
+void run_cold(float *W, float *out, const char *name, int nblocks) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f, bmean = 0.f;
+    for (int it = 0; it < 6; ++it) {
+        hipLaunchKernelGGL(k_write, dim3(64), dim3(256), 0, 0, W, 32768 * (SHAPE == 2 ? 256 : 1), (float)it);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((k<SHAPE, INFLIGHT>), dim3(nblocks), dim3(256), 0, 0, W, out, 1);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[512];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_t), sizeof(h));
+        unsigned long long t0 = ~0ull, t1 = 0; double sum = 0;
+        for (int b = 0; b < nblocks; ++b) { if (h[2*b] < t0) t0 = h[2*b]; if (h[2*b+1] > t1) t1 = h[2*b+1]; sum += (double)(h[2*b+1] - h[2*b]); }
+        const float span = (t1 - t0) / 100.0f, mean = (float)(sum / nblocks / 100.0);
+        if (it >= 2 && span < best) { best = span; bmean = mean; }
+    }
+    printf("COLD %-30s %3d blocks, in flight %2d KB/wave: span %6.2f us, mean block %5.2f us = %6.1f GB/s per CU\n", name, nblocks, INFLIGHT,
+           best, bmean, 128.0 * 1024 / (bmean * 1e-6) / 1e9);
+}
+int main() {
+    float *W, *out;
+    hipMalloc(&W, 256u * 128 * 1024); hipMemset(W, 0, 256u * 128 * 1024); hipMalloc(&out, 4096);
+    run<0, 4>(W, out, "16 rows x 64 B, shared region");
+    run<0, 8>(W, out, "16 rows x 64 B, shared region");
+    run<0, 16>(W, out, "16 rows x 64 B, shared region");
+    run<1, 4>(W, out, "1 KB contiguous, shared region");
+    run<1, 8>(W, out, "1 KB contiguous, shared region");
+    run<1, 16>(W, out, "1 KB contiguous, shared region");
+    run<2, 8>(W, out, "16 rows x 64 B, region per CU");
+    run<2, 16>(W, out, "16 rows x 64 B, region per CU");
+    run_cold<0, 8>(W, out, "16 rows x 64 B, shared", 256);
+    run_cold<0, 16>(W, out, "16 rows x 64 B, shared", 256);
+    run_cold<0, 32>(W, out, "16 rows x 64 B, shared", 256);
+    run_cold<1, 16>(W, out, "1 KB contiguous, shared", 256);
+    run_cold<1, 32>(W, out, "1 KB contiguous, shared", 256);
+    run_cold<0, 16>(W, out, "16 rows x 64 B, shared", 32);
+    run_cold<0, 16>(W, out, "16 rows x 64 B, shared", 8);
+    run_cold<2, 16>(W, out, "16 rows x 64 B, per CU", 256);
+    // an empty-ish kernel for the fixed cost of a launch measured the same way
+    run_cold<0, 1>(W, out, "(1 KB per wave in flight)", 256);
+    return 0;
+}
