@@ -64,10 +64,20 @@ struct Ctl {                       // device-resident state of the entropy coeff
 
 struct AlphaStep { float alpha, alpha_loss, log_alpha, m, v; };
 
+// Weight matrices live in HBM in FRAGMENT-MAJOR order: the 16x16 block (row tile, k-chunk) of a [rows][ld] matrix is
+// 1 KB contiguous, in MFMA operand order -- lane l = (row & 15) + 16 * ((k & 15) >> 2) holds the four floats k & 3.
+// One wave-instruction of the weight stream (a 16x16 fragment, 16 B per lane) then reads 8 whole 128-B lines instead
+// of 16 half lines: a kernel's first pass over freshly written weights (cold L2, every step) is bound by the number
+// of cache lines per instruction -- scratch/vmem_wall.hip: 66 GB/s per CU for 1 KB-contiguous instructions against
+// 33 GB/s for 16 rows x 64 B.
+__host__ __device__ __forceinline__ size_t frag_off(int row, int k, int ld) {
+    return ((size_t)(row >> 4) * (ld >> 4) + (k >> 4)) * 256 + (size_t)(((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3));
+}
+
 struct Layer {                     // one nn.Linear in the padded device layout
     int N, K, Np, Kp;
-    long long offW, offB;          // in P / M / V / G : W [Np][Kp], b [Np]
-    long long offWt;               // in PT / MT / VT : W^T [Kp + 16][Np]
+    long long offW, offB;          // in P / M / V / G : W [Np][Kp] fragment-major (frag_off), b [Np]
+    long long offWt;               // in PT / MT / VT : W^T [Kp + 16][Np] fragment-major (frag_off)
 };
 
 struct Net {
@@ -215,7 +225,7 @@ __device__ __forceinline__ AlphaStep alpha_step(const Ctl *ctl, const float *par
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
 // Weight stream of one wave: NT column tiles of 16 outputs, k-chunks of 16 held in a D-deep
-// register ring.  W is [n][ldw] (ldw % 4 == 0); lane (c = lane&15, g = lane>>4) loads the 16 B
+// register ring.  W is [n][ldw] in fragment-major order (frag_off); lane (c = lane&15, g = lane>>4) loads the 16 B
 // W[n0_t + c][16 S + 4 g .. +3], i.e. lane group g owns contraction index k = 16S + 4g + i.
 template <int NT, int D = RD>
 struct WRing {
@@ -225,7 +235,7 @@ struct WRing {
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            wp[t] = W + (size_t)(n_base + t * n_stride + (lane & 15)) * ldw + 4 * (lane >> 4) + 16 * s_off;
+            wp[t] = W + ((size_t)((n_base + t * n_stride) >> 4) * (ldw >> 4) + s_off) * 256 + 4 * lane;   // frag_off of this lane's 16 B
     }
     // chunks [u0, u1) of the first min(D, KS): the prologues issue a ring in pieces between independent
     // work -- a wave whose loads outrun the CU's fill path (~20 B/clk) just stalls at issue
@@ -234,7 +244,7 @@ struct WRing {
         for (int u = 0; u < D; ++u)
             if (u >= u0 && u < u1 && u < KS && u >= lo) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 16 * u);
+                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 256 * u);
             }
     }
     __device__ __forceinline__ void fill(int KS) {        // chunks 0 .. min(D, KS)-1 into flight
@@ -242,7 +252,7 @@ struct WRing {
         for (int u = 0; u < D; ++u)
             if (u < KS) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 16 * u);
+                for (int t = 0; t < NT; ++t) b[u][t] = ld4(wp[t] + 256 * u);
             }
     }
 };
@@ -281,7 +291,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 }
                 if (S + D < KS) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 16 * (S + D));
+                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 256 * (S + D));
                 }
                 SB();
 #pragma unroll
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
             rh.init(P + L2.offW, H, 0, 16, 4 * NTW * part + NTW * wave);                               \
             rh.fill(NTW);                                                                              \
         } else {                                                                                       \
-            _Pragma("unroll") for (int u = 0; u < 4 * NTW; ++u) w3[u] = P[L2.offW + SW * part + p16 + 16 * u]; \
+            _Pragma("unroll") for (int u = 0; u < 4 * NTW; ++u) w3[u] = P[L2.offW + frag_off(0, SW * part + p16 + 16 * u, H)]; \
         }                                                                                              \
         SB();                                                                                          \
     } while (0)
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     for (int t = 0; t < NTW; ++t) bv1[t] = PQ[d.LQ[1].offB + n0 + 16 * t + c];
     float w3[4 * NTW];
 #pragma unroll
-    for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + SW * part + a + 16 * u];
+    for (int u = 0; u < 4 * NTW; ++u) w3[u] = PQ[d.LQ[2].offW + frag_off(0, SW * part + a + 16 * u, H)];
     SB();
     const float lsum = group16_sum(lp);
     if (own_s && a == 0) red[row] = (grow < d.Bt) ? lsum : 0.f;          // (pad rows carry no weight)
@@ -829,7 +839,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
             rw.init(PT + d.LQ[1].offWt, H, 64 * wave, 16, 4 * NTW * part);
             rw.fill(4 * NTW);
         }
-        ra.init(PT + d.LQ[0].offWt + (size_t)d.KP * H, H, 0, 16, 4 * wave);
+        ra.init(PT + d.LQ[0].offWt, H, d.KP, 16, 4 * wave);      // rows KP.. of W1^T = the action columns
         ra.fill(4);
         SB();
     }
@@ -949,7 +959,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
         in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
     }
     const int k = threadIdx.x;
-    const float wk = P[d.LQ[2].offW + k];
+    const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
     f32x4 h2v[4];
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
         const int k_own = k0 + 16 * wave + r;
         const bool own_valid = k_own < J.K;
-        const size_t ot = (size_t)k_own * J.ldt + n0 + 4 * g;
+        const size_t ot = frag_off(k_own, n0 + 4 * g, J.ldt);    // this lane's 16 B of the transposed copy / Adam moments
         const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)k0 * B;
         const float *YT = J.dYT + (size_t)n0 * B;
         const int per = (B / 16) / 4;                 // 16-row chunks of the batch per wave
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + 4 * g + i;
-                if (n < J.N) tp4[i] = J.TP[(size_t)n * J.ldp + k_own];
+                if (n < J.N) tp4[i] = J.TP[frag_off(n, k_own, J.ldp)];
             }
         }
         float pb = 0.f, mbv = 0.f, vbv = 0.f, tbv = 0.f;
@@ -1390,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
                     float p = p4[i], m = m4[i], v = v4[i];
                     adam_update(p, m, v, gsum[i], step_size, bc2s);
                     p4[i] = p; m4[i] = m; v4[i] = v;
-                    const size_t o = (size_t)n * J.ldp + k_own;
+                    const size_t o = frag_off(n, k_own, J.ldp);
                     J.P[o] = p;
                     if (J.G) J.G[o] = gsum[i];
                     if (polyak) J.TP[o] = tp4[i] * (1.0f - d.tau) + p * d.tau;
@@ -1951,8 +1961,8 @@ static int upload_padded(sac_trainer *t, int net, const float *flat, float *devb
         const Layer &L = n.L[l];
         if (is_b) P[L.offB + nn] = flat[fi];
         else {
-            P[L.offW + (size_t)nn * L.Kp + k] = flat[fi];
-            if (also_transposed) PT[L.offWt + (size_t)k * L.Np + nn] = flat[fi];
+            P[L.offW + frag_off(nn, k, L.Kp)] = flat[fi];
+            if (also_transposed) PT[L.offWt + frag_off(k, nn, L.Np)] = flat[fi];
         }
     });
     SAC_HIP(hipMemcpyAsync(devbuf, P.data(), sizeof(float) * P.size(), hipMemcpyHostToDevice, t->stream));
@@ -1975,7 +1985,7 @@ static int download_padded(sac_trainer *t, int net, const float *devbuf, float *
     for_each_param(t, net, [&](int64_t fi, int l, int nn, int k, bool is_b) {
         const Layer &L = n.L[l];
         if (is_b) flat[fi] = P[L.offB + nn];
-        else flat[fi] = devT ? PT[L.offWt + (size_t)k * L.Np + nn] : P[L.offW + (size_t)nn * L.Kp + k];
+        else flat[fi] = devT ? PT[L.offWt + frag_off(k, nn, L.Np)] : P[L.offW + frag_off(nn, k, L.Kp)];
     });
     return 0;
 }
