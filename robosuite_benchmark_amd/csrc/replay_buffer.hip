@@ -92,7 +92,7 @@ __global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, ui
 // k_gather: persistent 256-thread workgroups, each moving 16-row blocks of minibatch slots:
 //   HBM rows (16-B aligned, padded stride) --dwordx4--> registers --> LDS tile --dwordx4--> slot.
 // The LDS tile lets the unpadded (B,O) output be written as full 16-B-per-lane coalesced stores
-// and lets the same rows be re-emitted feature-major (saT[KQ][B]) for the weight-gradient kernel.
+// and lets the same rows be re-emitted feature-major (saT[KQ][B], fragment-major: frag_off) for the weight-gradient kernel.
 // Three-stage software pipeline per workgroup (indices of block n+2, rows of block n+1, write-out
 // of block n), so a workgroup always has a row burst in flight while it stores: the gather is
 // bound by bytes in flight per CU, not by the two dependent round trips (index -> row) per block.
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                 float4 v;
                 v.x = lds[ms[0]]; v.y = lds[ms[1]]; v.z = lds[ms[2]]; v.w = lds[ms[3]];
                 const int f = tid >> 2, frow = (f < O) ? f : L.KA + (f - O);
-                *reinterpret_cast<float4 *>(S + L.off_saT + (int64_t)frow * B + row0 + 4 * (tid & 3)) = v;
+                *reinterpret_cast<float4 *>(S + L.off_saT + frag_off(frow, row0 + 4 * (tid & 3), B)) = v;   // fragment-major
             }
             lds_barrier();                         // tile free for the next block
             return;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                     const int r = 4 * q + j;
                     pv[j] = (f < O) ? t_obs[r * Ost + f] : t_act[r * Ast + (f - O)];
                 }
-                *reinterpret_cast<float4 *>(T + (int64_t)((f < O) ? f : L.KA + (f - O)) * B + row0 + 4 * q) = v;
+                *reinterpret_cast<float4 *>(T + frag_off((f < O) ? f : L.KA + (f - O), row0 + 4 * q, B)) = v;
             }
         }
         lds_barrier();                             // tile free for the next block

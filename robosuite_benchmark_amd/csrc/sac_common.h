@@ -36,6 +36,17 @@ constexpr int MT_M = 397;
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Weight matrices AND the feature-major activations ([feature][batch]: rows = features, k = batch row) live in HBM in
+// FRAGMENT-MAJOR order: the 16x16 block (row tile, k-chunk) of a [rows][ld] matrix is
+// 1 KB contiguous, in MFMA operand order -- lane l = (row & 15) + 16 * ((k & 15) >> 2) holds the four floats k & 3.
+// One wave-instruction of the weight stream (a 16x16 fragment, 16 B per lane) then reads 8 whole 128-B lines instead
+// of 16 half lines: a kernel's first pass over freshly written weights (cold L2, every step) is bound by the number
+// of cache lines per instruction -- scratch/vmem_wall.hip: 66 GB/s per CU for 1 KB-contiguous instructions against
+// 33 GB/s for 16 rows x 64 B.
+static inline __host__ __device__ size_t frag_off(int row, int k, int ld) {
+    return ((size_t)(row >> 4) * (ld >> 4) + (k >> 4)) * 256 + (size_t)(((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3));
+}
+
 // Layout of one minibatch slot in HBM (floats).  Written by the gather kernel, read by the step
 // kernels.  Row-major part == what random_batch returns; saT is the feature-major copy
 // [KQ][B] of the Q-net input that the weight-gradient kernel contracts over the batch.  The Q-net input is laid

@@ -64,16 +64,6 @@ struct Ctl {                       // device-resident state of the entropy coeff
 
 struct AlphaStep { float alpha, alpha_loss, log_alpha, m, v; };
 
-// Weight matrices live in HBM in FRAGMENT-MAJOR order: the 16x16 block (row tile, k-chunk) of a [rows][ld] matrix is
-// 1 KB contiguous, in MFMA operand order -- lane l = (row & 15) + 16 * ((k & 15) >> 2) holds the four floats k & 3.
-// One wave-instruction of the weight stream (a 16x16 fragment, 16 B per lane) then reads 8 whole 128-B lines instead
-// of 16 half lines: a kernel's first pass over freshly written weights (cold L2, every step) is bound by the number
-// of cache lines per instruction -- scratch/vmem_wall.hip: 66 GB/s per CU for 1 KB-contiguous instructions against
-// 33 GB/s for 16 rows x 64 B.
-__host__ __device__ __forceinline__ size_t frag_off(int row, int k, int ld) {
-    return ((size_t)(row >> 4) * (ld >> 4) + (k >> 4)) * 256 + (size_t)(((row & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3));
-}
-
 struct Layer {                     // one nn.Linear in the padded device layout
     int N, K, Np, Kp;
     long long offW, offB;          // in P / M / V / G : W [Np][Kp] fragment-major (frag_off), b [Np]
@@ -501,7 +491,7 @@ template <int NT>
 __device__ __forceinline__ void store_features(const f32x4 (&v)[NT], int n_base, int n_stride, float *outT, int B, int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) st4(outT + (size_t)(n_base + t * n_stride + c) * B + row0 + 4 * g, v[t]);
+    for (int t = 0; t < NT; ++t) st4(outT + frag_off(n_base + t * n_stride + c, row0 + 4 * g, B), v[t]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -530,7 +520,7 @@ constexpr int ring_depth(int ntw) { return ntw == 1 ? 8 : 4; }   // k-chunks in 
 // feature-major global rows of those features
 template <int NTW>
 __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const float (&bv)[NTW], int wave, float *XS,
-                                               float *outT /* row of feature n_first */, int B, int row0) {
+                                               float *outT, int n_first, int B, int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
@@ -540,7 +530,7 @@ __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const fl
             v[i] = fmaxf(acc[t][i] + bv[t], 0.f);
             XS[lds_off(4 * g + i, 16 * (NTW * wave + t) + c, 64 * NTW)] = v[i];
         }
-        if (outT) st4(outT + (size_t)(16 * t + c) * B + row0 + 4 * g, v);
+        if (outT) st4(outT + frag_off(n_first + 16 * t + c, row0 + 4 * g, B), v);
     }
 }
 
@@ -644,7 +634,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
             if (MODE == M_SAC && !is_pi && !WIDE) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
         }
         float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
-        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
+        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T, n0, B, row0);
     }
     lds_barrier();
     STAMP(0, 3);
@@ -732,9 +722,9 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     float abat = 0.f;                                        // the batch action a (act_only blocks)
     if (act_only) {
         abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
-        const float *qu = d.QU + ((size_t)p4 * H + 64 * wave + c) * B + row0 + 4 * (lane >> 4);
+        const float *qu = d.QU + (size_t)p4 * H * B + frag_off(64 * wave + c, row0 + 4 * (lane >> 4), B);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { acc0[t] = ld4(qu + (size_t)16 * t * B); bv0[t] = 0.f; }
+        for (int t = 0; t < 4; ++t) { acc0[t] = ld4(qu + (size_t)t * (B >> 4) * 256); bv0[t] = 0.f; }   // next feature tile
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv0[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
@@ -871,7 +861,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
             if (MODE == M_SAC && a == 0) d.logpi2[grow] = lsum;
         }
         float *h2T = (p4 < 2) ? d.QH2T + (size_t)pass * H * B : nullptr;
-        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T ? h2T + (size_t)n0 * B : nullptr, B, row0);
+        slice_epilogue<NTW>(acc, bv1, wave, XS, h2T, n0, B, row0);
     }
     lds_barrier();
     float s = 0.f;
@@ -962,7 +952,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
     f32x4 h2v[4];
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + (size_t)k * B + row0 + 4 * qd);
+    for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + frag_off(k, row0 + 4 * qd, B));
     SB();
     WRing<NTW, ring_depth(NTW)> r1;
     r1.init(PT + d.LQ[1].offWt, H, n0, 16);
@@ -970,7 +960,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
     SB();
     f32x4 h1v[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(h1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
+    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(h1T + frag_off(n0 + 16 * t + c, row0 + 4 * g, B));
     SB();
     // (scalar loads + a few scalar flops; placed behind the vector-load burst so its s_waitcnt does not delay it)
     float alpha = 0.f;                                                   // (TD3: no entropy term in the target)
@@ -1012,19 +1002,19 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
         if (threadIdx.x < RB && part == 0) {
             const int r = row0 + threadIdx.x;
             d.q[(size_t)qi * B + r] = vq;
-            d.dq16T[(size_t)qi * 16 * B + r] = dq;                      // row 0 of the padded [16][B]
+            d.dq16T[(size_t)qi * 16 * B + frag_off(0, r, B)] = dq;      // row 0 of the padded [16][B]
             if (qi == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
         }
         if ((k / SW) == part) {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) st4(d.dQH2T + (size_t)qi * H * B + (size_t)k * B + row0 + 4 * qd, gv2[qd]);
+            for (int qd = 0; qd < 4; ++qd) st4(d.dQH2T + (size_t)qi * H * B + frag_off(k, row0 + 4 * qd, B), gv2[qd]);
         }
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
             f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
-            st4(d.dQH1T + (size_t)qi * H * B + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
+            st4(d.dQH1T + (size_t)qi * H * B + frag_off(n0 + 16 * t + c, row0 + 4 * g, B), gv);
         }
     }
 }
@@ -1074,7 +1064,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     rh.fill(NTH);
     f32x4 h2v[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + (size_t)(64 * wave + 16 * t + c) * B + row0 + 4 * g);
+    for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
     SB();
     WRing<NTW, ring_depth(NTW)> r1;
     r1.init(PT + d.LP[1].offWt, H, n0, 16);
@@ -1082,7 +1072,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     SB();
     f32x4 h1v[NTW];
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(d.PH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g);
+    for (int t = 0; t < NTW; ++t) h1v[t] = ld4(d.PH1T + frag_off(n0 + 16 * t + c, row0 + 4 * g, B));
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
     float alpha = 0.f;
@@ -1144,8 +1134,8 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
         if (part == 0) {
             if (a == 0) { d.q[2 * (size_t)B + row0 + row] = qnew1; d.q[3 * (size_t)B + row0 + row] = qnew2; }
             if (a < A) {
-                d.dheadT[(size_t)a * B + row0 + row] = dz;
-                if constexpr (MODE == M_SAC) d.dheadT[(size_t)(A + a) * B + row0 + row] = dls;
+                d.dheadT[frag_off(a, row0 + row, B)] = dz;
+                if constexpr (MODE == M_SAC) d.dheadT[frag_off(A + a, row0 + row, B)] = dls;
             }
         }
         if (wave / NTW == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
@@ -1154,7 +1144,7 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
             f32x4 gv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) gv[i] = (h1v[t][i] > 0.f) ? acc[t][i] : 0.f;
-            st4(d.dPH1T + (size_t)(n0 + 16 * t + c) * B + row0 + 4 * g, gv);
+            st4(d.dPH1T + frag_off(n0 + 16 * t + c, row0 + 4 * g, B), gv);
         }
     }
 }
@@ -1309,14 +1299,16 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         const int k_own = k0 + 16 * wave + r;
         const bool own_valid = k_own < J.K;
         const size_t ot = frag_off(k_own, n0 + 4 * g, J.ldt);    // this lane's 16 B of the transposed copy / Adam moments
-        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)k0 * B;
-        const float *YT = J.dYT + (size_t)n0 * B;
+        // dY^T and X^T are fragment-major [feature][batch]: feature tile f, batch chunk q = 1 KB at ((f * B/16) + q) * 256
+        const size_t tile_floats = (size_t)(B >> 4) * 256;
+        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)(k0 >> 4) * tile_floats;
+        const float *YT = J.dYT + (size_t)(n0 >> 4) * tile_floats;
         const int per = (B / 16) / 4;                 // 16-row chunks of the batch per wave
         const int rem = (B / 16) - 4 * per;
         const int s0 = wave * per + (wave < rem ? wave : rem);
         const int s1 = s0 + per + (wave < rem ? 1 : 0);
-        const float *yp = YT + (size_t)r * B + 4 * g;
-        const float *xp = XT + (size_t)r * B + 4 * g;
+        const float *yp = YT + 4 * lane;              // this lane's 16 B of a fragment: (feature r, batch rows 4g..4g+3)
+        const float *xp = XT + 4 * lane;
         f32x4 acc[4] = {};
         float bsum = 0.f;
         // first group of operand loads, then the owner's state, then the scalars: all in flight together.
@@ -1328,9 +1320,9 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cq = chunk_of(s0 + u);
-            a[u] = ld4(yp + 16 * cq);
+            a[u] = ld4(yp + 256 * cq);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + (size_t)16 * t * B + 16 * cq);
+            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + t * tile_floats + 256 * cq);
         }
         f32x4 p4 = {0.f, 0.f, 0.f, 0.f}, m4 = p4, v4 = p4;
         if (own_valid) {
@@ -1375,9 +1367,9 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int cq = chunk_of(sI + 4 + u);
-                    a[u] = ld4(yp + 16 * cq);
+                    a[u] = ld4(yp + 256 * cq);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + (size_t)16 * t * B + 16 * cq);
+                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + t * tile_floats + 256 * cq);
                 }
             }
         }
@@ -2070,8 +2062,8 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     memcpy(sr, rew, sizeof(float) * Bt); memcpy(stt, term, sizeof(float) * Bt);
     memcpy(sn, next_obs, sizeof(float) * Bt * O);
     for (int b = 0; b < Bt; ++b) {
-        for (int k = 0; k < O; ++k) sT[(size_t)k * B + b] = obs[(size_t)b * O + k];
-        for (int k = 0; k < A; ++k) sT[(size_t)(L.KA + k) * B + b] = act[(size_t)b * A + k];
+        for (int k = 0; k < O; ++k) sT[frag_off(k, b, B)] = obs[(size_t)b * O + k];
+        for (int k = 0; k < A; ++k) sT[frag_off(L.KA + k, b, B)] = act[(size_t)b * A + k];
     }
     float *E = t->ext_slot;
     SAC_HIP(hipMemcpyAsync(E + L.off_obs, so, sizeof(float) * B * O, hipMemcpyHostToDevice, s));
