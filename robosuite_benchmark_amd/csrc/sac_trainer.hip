@@ -266,29 +266,29 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
         for (int u = 0; u < D; ++u) {
             const int S = S0 + u;
             if (S < KS) {
-                // next chunk's A fragment (LDS) and the refill of this ring slot (global) are issued
-                // BEFORE this chunk's 4*NT MFMAs and may not sink below them
+                // next chunk's A fragment (LDS) is requested in front of this chunk's MFMAs; the MFMAs read the ring slot
+                // in place (an MFMA takes its operands at issue) and the slot's refill (global) is requested right
+                // behind them -- no copy-out of the slot, whose v_movs would serialise with the MFMAs of a wave that
+                // has the SIMD to itself
                 const int Sn = (S + 1 < KS) ? S + 1 : S;
                 const f32x4 a_nxt = ld4(xrow + 4 * ((4 * (Sn + s_off) + g) ^ r));
-                f32x4 bc[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) bc[t] = R.b[u][t];
                 if constexpr (STAGED) {     // (compile-time: a run-time test here made hipcc mis-order the MFMAs' waits)
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) stage[(16 * S + 4 * g + i) * WLD + 16 * t + r] = bc[t][i];
-                }
-                if (S + D < KS) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 256 * (S + D));
+                        for (int i = 0; i < 4; ++i) stage[(16 * S + 4 * g + i) * WLD + 16 * t + r] = R.b[u][t][i];
                 }
                 SB();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], bc[t][i], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][t][i], acc[t], 0, 0, 0);
+                }
+                SB();
+                if (S + D < KS) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) R.b[u][t] = ld4(R.wp[t] + 256 * (S + D));
                 }
                 SB();
                 a_cur = a_nxt;
