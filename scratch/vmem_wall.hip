@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k(const float *__restrict__ W, float *out
                 const int S = s0 + u;                 // 0..31
                 const float *p;
                 if (SHAPE == 1) p = base + (size_t)(wave * 32 + S) * 256 + 4 * l;
+                else if (SHAPE == 3) p = base + (size_t)((wave * 32 + S + 4 * (blockIdx.x >> 3)) & 127) * 256 + 4 * l;   // rotated start per CU of an XCD
                 else p = base + (size_t)(wave * 32 + (S >> 4) * 16 + c) * 256 + 16 * (S & 15) + 4 * g;   // 16 rows of 1 KB, chunk S&15
                 v[u] = *reinterpret_cast<const f4 *>(p);
             }
@@ -91,6 +92,8 @@ int main() {
     run_cold<0, 32>(W, out, "16 rows x 64 B, shared", 256);
     run_cold<1, 16>(W, out, "1 KB contiguous, shared", 256);
     run_cold<1, 32>(W, out, "1 KB contiguous, shared", 256);
+    run_cold<3, 16>(W, out, "1 KB contiguous, shared, rotated", 256);
+    run_cold<3, 32>(W, out, "1 KB contiguous, shared, rotated", 256);
     run_cold<0, 16>(W, out, "16 rows x 64 B, shared", 32);
     run_cold<0, 16>(W, out, "16 rows x 64 B, shared", 8);
     run_cold<2, 16>(W, out, "16 rows x 64 B, per CU", 256);
