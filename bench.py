@@ -6,18 +6,25 @@ one full SAC gradient step (rlkit_custom.py:234-238 of the reference), with the 
 already resident in HBM when the timed region starts.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1: BASELINE.json configs[1] (Lift-Panda-OSC-POSE: obs 42 / act 7, batch 256, 1e6-slot buffer, full).
 N > 1: one independent replica per GPU (independent seed of the same workload; `--sweep` runs the
 8-task sweep of configs[4] instead), no data-path collective, one RCCL all-gather of the per-GPU
 results at the end ("weak" scaling).  Rank 0 prints ONE JSON line.
+
+Launching N > 1: either under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as plain `python bench.py --gpus N`: the parent then
+starts N child ranks itself (one per GPU, before it has touched any GPU API), relays rank 0's JSON line and
+exits non-zero if any rank failed -- the reference's own scale-out is "one job per config"
+(/root/reference/launch_jobs.sh:15-24).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,8 +36,9 @@ sys.path.insert(0, ROOT)
 from robosuite_benchmark_amd import parallel  # noqa: E402
 
 H = 256
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)" (spec)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+EXTRA_TASKS = [("TwoArmLift", 89, 14), ("LiftModded", 64, 4)]
 
 
 def flops_per_kernel(B, O, A):
@@ -45,18 +53,27 @@ def flops_per_kernel(B, O, A):
     }
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/*pmc_traffic.json; collected offline: PMC passes cannot run inside this process)."""
+def workload_tag(task, B):
+    return f"{task.lower()}_b{B}"
+
+
+def pmc_traffic(kernel, tag):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary of THIS workload
+    (profiles/*<tag>*pmc_traffic.json; collected offline by scripts/profile_round.sh: PMC passes cannot run inside
+    this process).  Older summaries without a workload tag are the Lift batch-256 ones."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return (k.get("traffic_bytes_per_launch") if k else None), os.path.relpath(files[-1], ROOT)
-    except Exception:
-        return None, None
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload", "lift_b256") != tag:
+            continue
+        k = d.get("kernels", {}).get(kernel)
+        if k:
+            return k.get("traffic_bytes_per_launch"), os.path.relpath(f, ROOT)
+    return None, None
 
 
 def gather_bytes_per_step(B, O, A):
@@ -75,6 +92,7 @@ def fill_buffer(buf, n, O, A, seed):
         rew = rs.uniform(0, 1, m).astype(np.float32)
         buf.add_block(obs, act, rew, nobs, np.zeros(m, np.uint8))       # terminals always 0 (ignore_done)
         done += m
+    buf.ingest_wait()                                                   # (inserts are asynchronous)
 
 
 def build_replica(task, O, A, B, n_buf, seed, device):
@@ -93,16 +111,30 @@ def build_replica(task, O, A, B, n_buf, seed, device):
     return trainer, buf
 
 
-def cpu_baseline(O, A, B, seconds_budget=24.0):
-    """The oracle (rlkit-equivalent torch restatement + reference-shaped float64 host buffer) timed on
-    this box's host cores: bounded sample of the same workload."""
+def measure_peaks(device):
+    """the roofline denominators measured on this box (also the clock warm-up of the run)."""
+    import ctypes as C
+    from robosuite_benchmark_amd import _lib
+    out = (C.c_float * 4)()
+    _lib.check(_lib.load().sac_measure_peaks(int(device), out), "sac_measure_peaks")
+    return dict(hbm_copy_gbs=round(float(out[0]), 1), fp32_mfma_tflops=round(float(out[1]), 2),
+                how="float4 stream copy of 1 GiB (read + write, best of 5 passes); back-to-back "
+                    "v_mfma_f32_16x16x4_f32 on 8 independent accumulators, one wave per SIMD x 4 (best of 3)")
+
+
+def cpu_baseline(O, A, B, n_host=1_000_000, budget_s=26.0):
+    """The oracle (rlkit-equivalent torch restatement + the reference-shaped float64 host buffer of the full
+    capacity) timed on this box's host cores, SURVEY.md 8d protocol: 50 warm-up steps, then repeats of 1000 steps,
+    median -- five repeats per thread setting unless the time budget cuts them (what was cut is stated)."""
     import torch
     from oracle.sac_step_torch import HostReplayBuffer, RlkitEquivalentSAC, init_sac_params, np_to_f32_batch
-    n_host = 100_000
     rs = np.random.RandomState(0)
     hb = HostReplayBuffer(n_host, O, A)
-    hb.fill_block(rs.normal(0, 0.5, (n_host, O)), rs.uniform(-1, 1, (n_host, A)), rs.uniform(0, 1, (n_host, 1)),
-                  np.zeros((n_host, 1), np.uint8), rs.normal(0, 0.5, (n_host, O)))
+    chunk = 250_000
+    for i in range(0, n_host, chunk):
+        m = min(chunk, n_host - i)
+        hb.fill_block(rs.normal(0, 0.5, (m, O)), rs.uniform(-1, 1, (m, A)), rs.uniform(0, 1, (m, 1)),
+                      np.zeros((m, 1), np.uint8), rs.normal(0, 0.5, (m, O)))
     sac = RlkitEquivalentSAC(init_sac_params(O, A, seed=0), A, policy_lr=1e-3, qf_lr=5e-4, soft_target_tau=0.005,
                              target_update_period=5)
     np.random.seed(17)
@@ -118,28 +150,31 @@ def cpu_baseline(O, A, B, seconds_budget=24.0):
 
     def timed(threads, budget):
         torch.set_num_threads(threads)
-        for _ in range(10):
+        for _ in range(50):
             one()
-        t0 = time.perf_counter()
-        n = 0
-        while True:
-            one()
-            n += 1
-            el = time.perf_counter() - t0
-            if el > budget or n >= 2000:
+        rates, t_start = [], time.perf_counter()
+        for rep in range(5):
+            t0 = time.perf_counter()
+            for _ in range(1000):
+                one()
+            rates.append(1000 / (time.perf_counter() - t0))
+            # stop when the next repeat would not fit the budget any more
+            if rep < 4 and (time.perf_counter() - t_start) * (rep + 2) / (rep + 1) > budget:
                 break
-        return n / el, n
+        return float(np.median(rates)), len(rates)
 
-    # eager torch on ~60 small ops per step does not scale with threads: time 1 thread and the box's
-    # CPU share, report the faster (torch's default of one thread per host CPU is far slower).
-    r1, n1 = timed(1, seconds_budget / 2)
-    rs_, ns = timed(share, seconds_budget / 2)
+    # eager torch on ~60 small ops per step does not scale with threads: 1 thread and the box's CPU share are both
+    # timed, the faster one is reported (torch's default of one thread per host CPU is far slower)
+    r1, n1 = timed(1, budget_s / 2)
+    rs_, ns = timed(share, budget_s / 2)
     torch.set_num_threads(default_threads)
     best, cores, n = (r1, 1, n1) if r1 >= rs_ else (rs_, share, ns)
+    cut = "" if n == 5 else f" (time budget cut the 5 repeats to {n})"
     return dict(value=round(best, 2), unit="grad-steps/s", cores=cores, kind="port",
-                sample=f"{n} steps of the same workload (batch {B}, obs {O}, act {A}) after 10 warm-up; "
-                       f"reference-shaped float64 host buffer of {n_host} rows; torch {torch.__version__} CPU eager; "
-                       f"1 thread: {r1:.1f}/s, {share} threads: {rs_:.1f}/s",
+                sample=f"median of {n} x 1000 steps of the same workload (batch {B}, obs {O}, act {A}) after 50 warm-up"
+                       f"{cut}; reference-shaped float64 host buffer of {n_host} rows, np.random.randint + fancy-index "
+                       f"gather + float32 cast + torch {torch.__version__} CPU eager step; "
+                       f"1 thread: {r1:.1f}/s ({n1} repeats), {share} threads: {rs_:.1f}/s ({ns} repeats)",
                 host_cpus=os.cpu_count())
 
 
@@ -242,6 +277,68 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device):
                 note="aggregate of independent runs sharing one GPU (100000-slot buffers); not the headline metric")
 
 
+# ---------------------------------------------------------------------------------------------------
+# N > 1 from plain `python bench.py --gpus N`: start the ranks ourselves
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank job.  Nothing here touches a GPU API (no torch.cuda, no HIP): the children
+    are started first and this process only waits, so no process that has initialised the GPU is ever re-executed.
+    Rank 0's stdout carries the JSON line; the other ranks' stdout goes to stderr.  Exit code != 0 if any rank fails."""
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = str(_free_port())
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:        # a rank that outlives rank 0 by minutes is stuck: end exactly that PID
+            p.kill()
+            rcs.append(p.wait())
+    if any(rc != 0 for rc in rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        if out0:
+            sys.stderr.write(out0)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise SystemExit(1)
+    lines = [l for l in (out0 or "").splitlines() if l.strip().startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n{out0}\n")
+        raise SystemExit(1)
+    print(lines[0], flush=True)
+
+
+class _DryTrainer:
+    """--dry-run: the launcher / rendezvous / timing / gathering plumbing of an N-rank job without any GPU.  A rank
+    "trains" by sleeping (rank r takes (r + 1) x the per-step time, so the max-over-ranks rule is visible)."""
+
+    def __init__(self, rank, ms_per_step):
+        self.rank, self.ms = rank, ms_per_step
+
+    def train_loop(self, buf, n, batch_size=None):
+        time.sleep(n * self.ms * (self.rank + 1) * 1e-3)
+        d = np.zeros(32, np.float32)
+        d[0], d[1], d[28] = 0.5 + self.rank, 0.25 + self.rank, 0.125
+        return d, d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,9 +351,14 @@ def main():
                     help="N=1 only: another task of the sweep table (e.g. Door, TwoArmHandoff); default Lift")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stepwise", action="store_true", help="skip the extra stepwise-interface data point")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peak microbenchmarks (spec peaks only)")
     ap.add_argument("--backend", type=str, default="nccl", help="collective backend for N>1 (nccl == RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal on a one-GPU box: every rank computes on device 0 (use with --backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU at all: ranks sleep instead of training (tests of the launcher and the N>1 plumbing; "
+                         "use with --backend gloo)")
+    ap.add_argument("--dry-run-ms-per-step", type=float, default=1.0)
     ap.add_argument("--profile-steps", type=int, default=500)
     ap.add_argument("--agent", type=str, default="SAC", choices=["SAC", "TD3"],
                     help="TD3: the SURVEY 8f row on the same workload shape (N=1, its own JSON line); default SAC = the headline metric")
@@ -268,30 +370,43 @@ def main():
         if args.gpus != 1:
             raise SystemExit("--agent TD3 is a single-GPU line")
         return td3_main(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])
     rank, local_rank, world = parallel.rank_info()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
-    import torch
     dist = None
     if world > 1:
         dist = parallel.init_process_group(args.backend, local_rank)   # nccl == RCCL on ROCm
     if args.single_device:
         local_rank = 0
+        # ranks sharing one GPU: the fused step's workgroups hand data to each other inside a launch and need the
+        # whole chip to themselves, so co-tenant ranks take the four-launch step
+        os.environ.setdefault("SAC_FUSED", "0")
 
     task, O, A, seed = parallel.task_for_rank(rank, sweep=args.sweep and world > 1)
     if args.task is not None and world == 1:
-        task, O, A = next(t for t in parallel.SWEEP + [("TwoArmLift", 89, 14)] if t[0] == args.task)
+        task, O, A = next(t for t in parallel.SWEEP + EXTRA_TASKS if t[0] == args.task)
     B = args.batch
-    trainer, buf = build_replica(task, O, A, B, args.buffer, seed=seed, device=local_rank)
+    peaks = None
+    if args.dry_run:
+        trainer, buf = _DryTrainer(rank, args.dry_run_ms_per_step), None
+        sync = lambda: None                                            # noqa: E731
+    else:
+        import torch
+        trainer, buf = build_replica(task, O, A, B, args.buffer, seed=seed, device=local_rank)
+        if world == 1 and not args.no_peaks:
+            peaks = measure_peaks(local_rank)                          # (before the timed region: also ramps the clocks)
+
+        def sync():
+            torch.cuda.synchronize()
+            trainer._lib.sac_sync(trainer._h)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
-        trainer._lib.sac_sync(trainer._h)
+        sync()
 
     # ---- warm-up (untimed), then EXACTLY K timed steps --------------------------------------
     if args.warmup > 0:
@@ -301,7 +416,6 @@ def main():
     first, last = trainer.train_loop(buf, args.steps, batch_size=B)      # returns after the stream drained
     barrier()
     elapsed = time.perf_counter() - t0
-    dev_ms = trainer.loop_timing_ms()
 
     elapsed_max = parallel.max_over_ranks(dist, elapsed)
     # the only collective of the job: per-GPU result vectors (steps/s, last losses, alpha) all-gathered
@@ -310,39 +424,7 @@ def main():
     out = None
     if rank == 0:
         value = parallel.aggregate_steps_per_second(world, args.steps, elapsed_max)
-        # ---- per-kernel durations: instrumented replay of the same loop (HIP events on the
-        #      launching streams), N=1 / rank 0 only ------------------------------------------
-        prof = trainer.profile_loop(buf, min(args.profile_steps, args.steps, 4096), batch_size=B)
-        fl = flops_per_kernel(B, O, A)
-        kern = {}
-        for k, f in fl.items():
-            ms = prof[k]
-            kern[k] = dict(ms=round(ms, 5), gflop=round(f / 1e9, 5), tflops=round(f / (ms * 1e-3) / 1e12, 3))
-        nprof = min(args.profile_steps, args.steps, 4096)
-        gb = gather_bytes_per_step(B, O, A) * nprof
-        kern["k_gather"] = dict(ms=round(prof["k_gather"], 5), bytes=gb,
-                                gbs=round(gb / (prof["k_gather"] * 1e-3) / 1e9, 2),
-                                frac_hbm=round(gb / (prof["k_gather"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
-        kern["k_mt_randint"] = dict(ms=round(prof["k_mt_randint"], 5), indices=nprof * B)
-        dom = max(fl, key=lambda k: prof[k])
-        # A launch's duration as rocprofv3's kernel trace reports it runs from dispatch to completion, i.e. it
-        # includes the ~2 us dispatch boundary (back-to-back launches: the trace's durations add up to the step).
-        # The event intervals above (minus the cost of an empty event pair) exclude it, so the boundary is added
-        # back: (timed step - sum of the intervals) / launches per step.  `achieved` uses that longer duration.
-        step_ms = elapsed_max / args.steps * 1e3
-        boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
-        dom_ms = prof[dom] + boundary_ms
-        achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom) if (B == 256 and O == 42) else (None, None)
-        roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), traffic=traffic,
-                        traffic_source=traffic_src, flops_per_launch=fl[dom], avg_launch_ms=round(dom_ms, 5),
-                        exec_ms=round(prof[dom], 5), dispatch_boundary_ms=round(boundary_ms, 5),
-                        achieved_exec=round(fl[dom] / (prof[dom] * 1e-3) / 1e12, 3),
-                        event_pair_ms=round(prof["event_pair"], 5),
-                        whole_step=dict(gflop=round(sum(fl.values()) / 1e9, 4),
-                                        tflops=round(sum(fl.values()) * value / world / 1e12, 3),
-                                        frac=round(sum(fl.values()) * value / world / 1e12 / PEAK_FP32_MFMA_TFLOPS, 5)))
+        tasks = [parallel.task_for_rank(r, sweep=args.sweep and world > 1) for r in range(world)]
         out = {
             "metric": "SAC grad-steps/sec (batch=256, 1e6 buffer) at 1/2/4/8 GPU" if B == 256 else
                       f"SAC grad-steps/sec (batch={B})",
@@ -357,40 +439,137 @@ def main():
                        "parallelism": ("independent task per GPU (8-task sweep)" if args.sweep and world > 1
                                        else "independent seed per GPU, no data-path collective") if world > 1
                        else "single GPU",
+                       "rank_tasks": [dict(rank=r, task=t[0], obs_dim=t[1], act_dim=t[2], seed=t[3])
+                                      for r, t in enumerate(tasks)],
                        "per_step": "MT19937 index draw + row gather + full SAC gradient step"},
-            "device_ms": {k: round(v, 3) for k, v in dev_ms.items()},
-            "roofline": roofline,
-            "roofline_gather": dict(bound="hbm", kernel="k_gather", achieved=kern["k_gather"]["gbs"], peak=PEAK_HBM_GBS,
-                                    unit="GB/s", frac=kern["k_gather"]["frac_hbm"],
-                                    algorithmic_bytes_per_step=gather_bytes_per_step(B, O, A), steps_per_launch=nprof),
-            "kernels": kern,
+            "elapsed_max_s": round(elapsed_max, 6),
             "per_gpu": per_gpu,
             "final": {"QF1 Loss": float(last[0]), "QF2 Loss": float(last[1]), "Alpha": float(last[28])},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(O, A, B)
-        elif world == 1:
-            out["cpu_baseline"] = None
-        if world == 1 and not args.no_stepwise:
-            # the reference's unmodified loop body (random_batch -> train) through the Python duck types, batches
-            # staying on the device (DeviceBatch): extra data point, never `value`
-            n_sw = min(args.steps, 2000)
-            for _ in range(50):
-                trainer.train(buf.random_batch(B))
-            trainer._lib.sac_sync(trainer._h)
-            t0 = time.perf_counter()
-            for _ in range(n_sw):
-                trainer.train(buf.random_batch(B))
-            trainer._lib.sac_sync(trainer._h)
-            out["stepwise_interface"] = dict(value=round(n_sw / (time.perf_counter() - t0), 2), unit="grad-steps/s", steps=n_sw,
-                                             note="replay_buffer.random_batch(B); trainer.train(batch) per step from Python")
-        if world == 1 and args.replicas_per_gpu > 1:
-            out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, local_rank)
+        if args.dry_run:
+            out["data"] = "none (--dry-run: ranks sleep instead of training; plumbing test only, not a measurement)"
+            out["dry_run"] = True
+        else:
+            out.update(device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, peaks, local_rank))
     barrier()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, peaks, device):
+    """Everything of the JSON line that comes from the device after the timed region (rank 0)."""
+    out = {"device_ms": {k: round(v, 3) for k, v in trainer.loop_timing_ms().items()}}
+    # ---- per-kernel durations: instrumented replay of the same loop (HIP events on the
+    #      launching streams) ------------------------------------------------------------------
+    nprof = min(args.profile_steps, args.steps, 4096)
+    prof = trainer.profile_loop(buf, nprof, batch_size=B)
+    fl_all = flops_per_kernel(B, O, A)
+    step_kernels = [k for k in prof if k.startswith("k_") and k not in ("k_gather", "k_mt_randint") and prof[k] > 0]
+    # a fused launch carries the FLOPs of the launches it replaces ("k_fwd_abc" = a + b + c ...)
+    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_fwd_bc": ("k_fwd_b", "k_bwd")}
+    fl = {k: (sum(fl_all[p] for p in fused_parts[k]) if k in fused_parts else fl_all[k]) for k in step_kernels}
+    kern = {}
+    for k, f in fl.items():
+        ms = prof[k]
+        kern[k] = dict(ms=round(ms, 5), gflop=round(f / 1e9, 5), tflops=round(f / (ms * 1e-3) / 1e12, 3))
+    gb = gather_bytes_per_step(B, O, A) * nprof
+    kern["k_gather"] = dict(ms=round(prof["k_gather"], 5), bytes=gb, steps_per_launch=nprof,
+                            gbs=round(gb / (prof["k_gather"] * 1e-3) / 1e9, 2))
+    kern["k_mt_randint"] = dict(ms=round(prof["k_mt_randint"], 5), indices=nprof * B)
+    dom = max(fl, key=lambda k: prof[k])
+    # A launch's duration as rocprofv3's kernel trace reports it runs from dispatch to completion, i.e. it
+    # includes the ~2 us dispatch boundary (back-to-back launches: the trace's durations add up to the step).
+    # The event intervals above (minus the cost of an empty event pair) exclude it, so the boundary is added
+    # back: (timed step - sum of the intervals) / launches per step.  `achieved` uses that longer duration.
+    # The step time is the DEVICE time of the timed loop (events on the trainer's stream), so the per-call fixed
+    # cost of a short loop does not leak into a kernel's duration.
+    step_ms = out["device_ms"]["steps"] / args.steps
+    boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
+    dom_ms = prof[dom] + boundary_ms
+    achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(dom, workload_tag(task, B))
+    pk_m = peaks["fp32_mfma_tflops"] if peaks else None
+    whole = sum(fl.values()) * value / world / 1e12
+    out["roofline"] = dict(
+        bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+        frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), peak_spec=PEAK_FP32_MFMA_TFLOPS, peak_measured=pk_m,
+        frac_measured=round(achieved / pk_m, 5) if pk_m else None, traffic=traffic, traffic_source=traffic_src,
+        flops_per_launch=fl[dom], avg_launch_ms=round(dom_ms, 5), exec_ms=round(prof[dom], 5),
+        dispatch_boundary_ms=round(boundary_ms, 5), achieved_exec=round(fl[dom] / (prof[dom] * 1e-3) / 1e12, 3),
+        event_pair_ms=round(prof["event_pair"], 5), launches_per_step=len(fl),
+        whole_step=dict(gflop=round(sum(fl.values()) / 1e9, 4), tflops=round(whole, 3),
+                        frac=round(whole / PEAK_FP32_MFMA_TFLOPS, 5),
+                        frac_measured=round(whole / pk_m, 5) if pk_m else None))
+    # ---- gather against the HBM roof, at K = 1 and K = 1000 steps per launch (SURVEY.md 8d) ------------
+    pk_h = peaks["hbm_copy_gbs"] if peaks else None
+    per_step = gather_bytes_per_step(B, O, A)
+
+    def gather_line(K, reps):
+        ms = float(np.median([buf.sample_gather_device(B, K)[1] for _ in range(reps)]))
+        gbs = per_step * K / (ms * 1e-3) / 1e9
+        return dict(steps_per_launch=K, launch_ms=round(ms, 5), achieved=round(gbs, 2), frac=round(gbs / PEAK_HBM_GBS, 5),
+                    frac_measured=round(gbs / pk_h, 5) if pk_h else None)
+
+    out["roofline_gather"] = dict(bound="hbm", kernel="k_gather", unit="GB/s", peak=PEAK_HBM_GBS, peak_spec=PEAK_HBM_GBS,
+                                  peak_measured=pk_h, algorithmic_bytes_per_step=per_step,
+                                  K1=gather_line(1, 21), K1000=gather_line(1000, 5),
+                                  in_loop=dict(steps_per_launch=nprof, achieved=kern["k_gather"]["gbs"],
+                                               frac=round(kern["k_gather"]["gbs"] / PEAK_HBM_GBS, 5)),
+                                  traffic=pmc_traffic("k_gather", workload_tag(task, B))[0])
+    out["peaks_measured"] = peaks
+    out["kernels"] = kern
+    # ---- fixed cost of one sac_train_loop call: t(n) = fixed + n * per_step from two loop lengths -------
+    if world == 1:
+        def loop_s(n):
+            ts = []
+            for _ in range(5):
+                trainer._lib.sac_sync(trainer._h)
+                t0 = time.perf_counter()
+                trainer.train_loop(buf, n, batch_size=B)
+                ts.append(time.perf_counter() - t0)
+            return float(np.median(ts))
+        t_a, t_b = loop_s(20), loop_s(520)
+        per = (t_b - t_a) / 500
+        out["fixed_call_us"] = round((t_a - 20 * per) * 1e6, 1)
+        out["short_loop"] = dict(steps=20, value=round(20 / t_a, 2), unit="grad-steps/s",
+                                 note="a 20-step sac_train_loop call timed like the headline (host wall, call to return)")
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(O, A, B, n_host=args.buffer)
+    elif world == 1:
+        out["cpu_baseline"] = None
+    if world == 1 and not args.no_stepwise:
+        # the reference's unmodified loop body (random_batch -> train) through the Python duck types, batches
+        # staying on the device (DeviceBatch): extra data point, never `value`
+        n_sw = min(args.steps, 2000)
+        for _ in range(50):
+            trainer.train(buf.random_batch(B))
+        trainer._lib.sac_sync(trainer._h)
+        t0 = time.perf_counter()
+        for _ in range(n_sw):
+            trainer.train(buf.random_batch(B))
+        trainer._lib.sac_sync(trainer._h)
+        out["stepwise_interface"] = dict(value=round(n_sw / (time.perf_counter() - t0), 2), unit="grad-steps/s", steps=n_sw,
+                                         note="replay_buffer.random_batch(B); trainer.train(batch) per step from Python")
+    if world == 1:
+        # asynchronous ingest (SURVEY.md 8f row 2): one epoch's 2 500 exploration rows; host-blocking time of the
+        # insert call vs the time until the rows have landed in HBM
+        rs = np.random.RandomState(5)
+        blk = (rs.normal(0, 0.5, (2500, O)), rs.uniform(-1, 1, (2500, A)), rs.uniform(0, 1, 2500),
+               rs.normal(0, 0.5, (2500, O)), np.zeros(2500, np.uint8))        # float64, the reference's native dtype
+        buf.ingest_wait()
+        t0 = time.perf_counter()
+        buf.add_block(*blk)
+        t1 = time.perf_counter()
+        buf.ingest_wait()
+        t2 = time.perf_counter()
+        out["ingest"] = dict(rows=2500, call_returns_us=round((t1 - t0) * 1e6, 1), landed_us=round((t2 - t0) * 1e6, 1),
+                             note="sac_buffer_add_f64 of one epoch's exploration steps: pack into pinned staging + enqueue "
+                                  "(call returns) vs rows resident in HBM")
+    if world == 1 and args.replicas_per_gpu > 1:
+        out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device)
+    return out
 
 
 if __name__ == "__main__":

@@ -52,6 +52,14 @@ int sac_buffer_add(sac_buffer_t *buf, int64_t n, const float *obs, const float *
                    const float *next_obs, const uint8_t *term);
 int sac_buffer_add_f64(sac_buffer_t *buf, int64_t n, const double *obs, const double *act, const double *rew,
                        const double *next_obs, const uint8_t *term);
+/* The inserts are ASYNCHRONOUS (ingest overlapping env stepping; the reference inserts 2 500
+ * rows per epoch between rollouts and training, /root/reference/util/rlkit_custom.py:223-231): rows are packed into
+ * one of two pinned staging buffers and handed to the copy engine on the buffer's stream; the call returns once the
+ * copies are enqueued, the caller's arrays are free for reuse, and size/top already count the rows.  Sampling,
+ * gathering and sac_buffer_read are ordered behind the inserts on that stream, so nobody has to wait explicitly;
+ * sac_buffer_ingest_pending polls (1 = rows still in flight), sac_buffer_ingest_wait blocks until they have landed. */
+int sac_buffer_ingest_pending(sac_buffer_t *buf);
+int sac_buffer_ingest_wait(sac_buffer_t *buf);
 int64_t sac_buffer_size(const sac_buffer_t *buf);      /* 'replay_buffer/size' */
 int64_t sac_buffer_top(const sac_buffer_t *buf);
 int64_t sac_buffer_capacity(const sac_buffer_t *buf);
@@ -221,6 +229,11 @@ int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float 
  * a reserved slot (0), k_dw_adam (each minus the cost of an empty event pair), that empty-pair cost,
  * and the wall ms of all n_steps steps}.  n_steps <= 4096. */
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float out_ms[9]);
+
+/* SURVEY.md 8d "Bounding roofline": the peaks the roofline fractions divide by, MEASURED on the box -- a float4
+ * stream copy of 1 GiB (read + write GB/s) and a back-to-back v_mfma_f32_16x16x4_f32 loop on every SIMD (TFLOP/s).
+ * out[4] = {copy GB/s, fp32 MFMA TFLOP/s, GB moved per copy pass, ms of the best MFMA pass}. */
+int sac_measure_peaks(int device, float out[4]);
 
 /* test access to intermediates of the last step: name in {"a_new","log_pi","mu","log_std","q1","q2",
  * "q_target","q1_new","q2_new","a_next","log_pi_next","g_policy","g_qf1","g_qf2"} (g_* = flat

@@ -40,15 +40,17 @@ TANH_EPS = 1e-6       # [R] TanhNormal epsilon
 #   Q nets : fc0, fc1, last_fc
 #   policy : fc0, fc1, last_fc (mean), last_fc_log_std
 # --------------------------------------------------------------------------------------
-def init_mlp_params(rs: np.random.RandomState, in_dim: int, hidden, heads, init_w: float):
+def init_mlp_params(rs: np.random.RandomState, in_dim: int, hidden, heads, init_w: float, b_init_value: float = 0.1):
     """Deterministic rlkit-style init ([R]: fanin_init uses size[0] of the (out,in) weight,
-    hidden bias constant 0, heads uniform(+-init_w)).  Init never enters per-step parity."""
+    hidden bias constant b_init_value -- 0.1 in the rlkit the reference pins (b7f97b2, before the networks
+    refactor that made it 0; unpinned: rlkit is not vendored and no shipped artefact holds an initial bias) --
+    heads uniform(+-init_w)).  Init never enters per-step parity."""
     params = []
     d = in_dim
     for h in hidden:
         bound = 1.0 / math.sqrt(h)
         params.append((rs.uniform(-bound, bound, size=(h, d)).astype(np.float32),
-                       np.zeros(h, dtype=np.float32)))
+                       np.full(h, b_init_value, dtype=np.float32)))
         d = h
     for n_out in heads:
         params.append((rs.uniform(-init_w, init_w, size=(n_out, d)).astype(np.float32),

@@ -61,6 +61,8 @@ SYMBOLS = {
     "sac_buffer_destroy": (C.c_int, [_P]),
     "sac_buffer_add": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
     "sac_buffer_add_f64": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "sac_buffer_ingest_pending": (C.c_int, [_P]),
+    "sac_buffer_ingest_wait": (C.c_int, [_P]),
     "sac_buffer_size": (C.c_int64, [_P]),
     "sac_buffer_top": (C.c_int64, [_P]),
     "sac_buffer_capacity": (C.c_int64, [_P]),
@@ -92,6 +94,7 @@ SYMBOLS = {
     "sac_sync": (C.c_int, [_P]),
     "sac_last_loop_ms": (C.c_int, [_P, _F, _F, _F, _F]),
     "sac_profile_loop": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "sac_measure_peaks": (C.c_int, [C.c_int, _F]),
     "sac_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "sac_policy_mirror": (C.c_int, [_P]),
     "sac_policy_act": (C.c_int, [_P, _P, C.c_int, _P, _P]),

@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["replay_buffer.hip", "sac_trainer.hip"]
+SOURCES = ["replay_buffer.hip", "sac_trainer.hip", "peaks.hip"]
 LIB = os.path.join(HERE, "libsac_hip.so")
 
 

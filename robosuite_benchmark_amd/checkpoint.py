@@ -16,34 +16,76 @@ from __future__ import annotations
 
 import json
 import os
+import shutil
 import zipfile
+import zlib
 from collections import OrderedDict
 
 import numpy as np
 
-FORMAT = "robosuite_benchmark_amd.checkpoint/1"
+FORMAT = "robosuite_benchmark_amd.checkpoint/1"     # (generations + CRC32 are additions the loader treats as optional)
 NETS = ("policy", "qf1", "qf2", "target_qf1", "target_qf2")
 
 
 def _save(dirname, manifest, name, arr):
     arr = np.ascontiguousarray(arr)
-    np.save(os.path.join(dirname, name + ".npy"), arr, allow_pickle=False)
-    manifest["arrays"][name] = dict(dtype=str(arr.dtype), shape=list(arr.shape))
+    path = os.path.join(dirname, name + ".npy")
+    with open(path, "wb") as f:
+        np.save(f, arr, allow_pickle=False)
+        f.flush()
+        os.fsync(f.fileno())
+    manifest["arrays"][name] = dict(dtype=str(arr.dtype), shape=list(arr.shape),
+                                    crc32=int(zlib.crc32(memoryview(arr).cast("B")) & 0xFFFFFFFF))
+
+
+def _fsync_dir(path):
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+    finally:
+        os.close(fd)
+
+
+def current_dir(dirname):
+    """The directory holding the newest COMPLETE save under `dirname`, or None.  Saves are generations
+    `<dirname>/gen-<n>/`; `<dirname>/latest` names the newest complete one and is replaced atomically, last."""
+    ptr = os.path.join(dirname, "latest")
+    if os.path.exists(ptr):
+        with open(ptr) as f:
+            sub = f.read().strip()
+        cand = os.path.join(dirname, sub)
+        if sub and os.path.exists(os.path.join(cand, "manifest.json")):
+            return cand
+        return None
+    if os.path.exists(os.path.join(dirname, "manifest.json")):       # flat layout of the first format revision
+        return dirname
+    return None
+
+
+def checkpoint_exists(dirname):
+    return current_dir(dirname) is not None
 
 
 def save_checkpoint(dirname, trainer, replay_buffer=None, extra=None):
-    """Write <dirname>/manifest.json + one .npy per array.  `extra`: JSON-serialisable dict (epoch, seed ...)."""
+    """Write a new generation `<dirname>/gen-<n>/` (manifest.json + one .npy per array), then flip `<dirname>/latest`
+    to it and drop the older generations.  Nothing of the previous save is touched before the pointer has flipped, so a
+    process killed at ANY point leaves either the old or the new save complete -- never a mix (every array also carries
+    a CRC32 in the manifest, checked on load).  `extra`: JSON-serialisable dict (epoch, seed ...)."""
     os.makedirs(dirname, exist_ok=True)
     if trainer._h is None:
         raise RuntimeError("the trainer owns no device state yet (construct it with batch_size= or train once)")
+    gens = sorted(int(d[4:]) for d in os.listdir(dirname) if d.startswith("gen-") and d[4:].isdigit())
+    sub = f"gen-{(gens[-1] + 1) if gens else 0}"
+    gdir = os.path.join(dirname, sub)
+    os.makedirs(gdir)
     man = dict(format=FORMAT, arrays=OrderedDict(), extra=extra or {})
     st = trainer.state_dict()
     for net, flat in st["params"].items():
-        _save(dirname, man, f"params.{net}", flat)
+        _save(gdir, man, f"params.{net}", flat)
     for net, (m, v) in st["opt"].items():
-        _save(dirname, man, f"adam_m.{net}", m)
-        _save(dirname, man, f"adam_v.{net}", v)
-    _save(dirname, man, "trainer_scalars", st["scalars"])      # log_alpha, its Adam m/v, adam_t, n_train_steps_total, alpha
+        _save(gdir, man, f"adam_m.{net}", m)
+        _save(gdir, man, f"adam_v.{net}", v)
+    _save(gdir, man, "trainer_scalars", st["scalars"])      # log_alpha, its Adam m/v, adam_t, n_train_steps_total, alpha
     man["trainer"] = dict(obs_dim=trainer.obs_dim, action_dim=trainer.act_dim, num_train_steps=trainer._num_train_steps,
                           batch_size=trainer._batch,
                           hparams={k: getattr(trainer, k) for k in (
@@ -52,45 +94,63 @@ def save_checkpoint(dirname, trainer, replay_buffer=None, extra=None):
     if replay_buffer is not None:
         bs = replay_buffer.state_dict()
         for k in ("observations", "actions", "rewards", "next_observations", "terminals", "rng_key"):
-            _save(dirname, man, "buffer." + k, bs[k])
+            _save(gdir, man, "buffer." + k, bs[k])
         man["buffer"] = {k: int(bs[k]) for k in ("capacity", "obs_dim", "action_dim", "top", "size", "rng_pos")}
-    tmp = os.path.join(dirname, "manifest.json.tmp")
-    with open(tmp, "w") as f:
+    with open(os.path.join(gdir, "manifest.json"), "w") as f:
         json.dump(man, f, indent=1)
-    os.replace(tmp, os.path.join(dirname, "manifest.json"))    # the manifest appears last: a torn save is detectable
+        f.flush()
+        os.fsync(f.fileno())
+    _fsync_dir(gdir)
+    tmp = os.path.join(dirname, "latest.tmp")
+    with open(tmp, "w") as f:
+        f.write(sub + "\n")
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, os.path.join(dirname, "latest"))          # the commit point
+    _fsync_dir(dirname)
+    for g in gens:                                             # older generations (and torn ones) go only now
+        shutil.rmtree(os.path.join(dirname, f"gen-{g}"), ignore_errors=True)
     return man
 
 
 def load_checkpoint(dirname, trainer, replay_buffer=None):
     """Restore trainer (and buffer) state saved by save_checkpoint; returns the manifest's `extra`."""
-    with open(os.path.join(dirname, "manifest.json")) as f:
+    cdir = current_dir(dirname)
+    if cdir is None:
+        raise FileNotFoundError(f"{dirname}: no complete checkpoint")
+    with open(os.path.join(cdir, "manifest.json")) as f:
         man = json.load(f)
     if man.get("format") != FORMAT:
-        raise ValueError(f"{dirname}: not a {FORMAT} checkpoint")
+        raise ValueError(f"{cdir}: not a {FORMAT} checkpoint")
 
     def arr(name):
-        a = np.load(os.path.join(dirname, name + ".npy"), allow_pickle=False)
+        a = np.load(os.path.join(cdir, name + ".npy"), allow_pickle=False)
         want = man["arrays"][name]
         if str(a.dtype) != want["dtype"] or list(a.shape) != want["shape"]:
-            raise ValueError(f"{dirname}/{name}.npy does not match the manifest")
+            raise ValueError(f"{cdir}/{name}.npy does not match the manifest")
+        if "crc32" in want and int(zlib.crc32(memoryview(np.ascontiguousarray(a)).cast("B")) & 0xFFFFFFFF) != want["crc32"]:
+            raise ValueError(f"{cdir}/{name}.npy: content does not match the manifest (torn or foreign file)")
         return a
 
     tm = man["trainer"]
     if (tm["obs_dim"], tm["action_dim"]) != (trainer.obs_dim, trainer.act_dim):
         raise ValueError("checkpointed trainer has other dimensions")
-    if trainer._h is None:
-        trainer._create(int(tm["batch_size"]))
+    # read and verify EVERYTHING before touching the live state
     st = dict(params={n: arr(f"params.{n}") for n in trainer.NETS},
               opt={n: (arr(f"adam_m.{n}"), arr(f"adam_v.{n}")) for n in ("policy", "qf1", "qf2")},
               scalars=arr("trainer_scalars"))
-    trainer.load_state_dict(st)
-    trainer._num_train_steps = int(tm["num_train_steps"])
+    bs = None
     if replay_buffer is not None:
         if "buffer" not in man:
-            raise ValueError(f"{dirname} holds no replay buffer")
+            raise ValueError(f"{cdir} holds no replay buffer")
         bs = dict(man["buffer"])
         for k in ("observations", "actions", "rewards", "next_observations", "terminals", "rng_key"):
             bs[k] = arr("buffer." + k)
+    if trainer._h is None:
+        trainer._create(int(tm["batch_size"]))
+    trainer.load_state_dict(st)
+    trainer._num_train_steps = int(tm["num_train_steps"])
+    if bs is not None:
         replay_buffer.load_state_dict(bs)
     return man.get("extra", {})
 

@@ -155,8 +155,10 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
     // The element -> (row, column) maps of the write-out are the same for every block: for narrow rows
     // (NIT == 1: one pass per thread) they are computed once, outside the block loop (the integer
     // divisions by the runtime row length otherwise dominate the write-out's instruction count).
-    int mo[4] = {0, 0, 0, 0}, ma[4] = {0, 0, 0, 0}, ms[4] = {0, 0, 0, 0};
-    const bool has_o = tid < ((RB * O) >> 2), has_a = tid < ((RB * A) >> 2), has_s = tid < (O + A) * 4;
+    // (feature-major copy: O + A <= 64 + 16 features x 4 row groups = up to 320 elements -> two passes of 256 threads)
+    int mo[4] = {0, 0, 0, 0}, ma[4] = {0, 0, 0, 0}, ms[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const bool has_o = tid < ((RB * O) >> 2), has_a = tid < ((RB * A) >> 2);
+    const bool has_s[2] = {tid < (O + A) * 4, tid + 256 < (O + A) * 4};
     if constexpr (NIT == 1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -164,8 +166,11 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
             mo[j] = has_o ? ro_ * Ost + (eo - ro_ * O) : 0;
             const int ea = 4 * tid + j, ra_ = ea / A;
             ma[j] = has_a ? ra_ * Ast + (ea - ra_ * A) : 0;
-            const int f = tid >> 2, r = 4 * (tid & 3) + j;
-            ms[j] = has_s ? ((f < O) ? r * Ost + f : 2 * RB * Ost + r * Ast + (f - O)) : 0;   // t_act follows t_nobs
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {
+                const int f = (tid + 256 * ps) >> 2, r = 4 * (tid & 3) + j;
+                ms[ps][j] = has_s[ps] ? ((f < O) ? r * Ost + f : 2 * RB * Ost + r * Ast + (f - O)) : 0;   // t_act follows t_nobs
+            }
         }
     }
 
@@ -197,12 +202,14 @@ __global__ __launch_bounds__(256) void k_gather(ReplayView rv, const int64_t *__
                 a.x = t_act[ma[0]]; a.y = t_act[ma[1]]; a.z = t_act[ma[2]]; a.w = t_act[ma[3]];
                 *reinterpret_cast<float4 *>(S + L.off_act + (int64_t)row0 * A + 4 * tid) = a;
             }
-            if (write_saT && has_s) {
-                float4 v;
-                v.x = lds[ms[0]]; v.y = lds[ms[1]]; v.z = lds[ms[2]]; v.w = lds[ms[3]];
-                const int f = tid >> 2, frow = (f < O) ? f : L.KA + (f - O);
-                *reinterpret_cast<float4 *>(S + L.off_saT + frag_off(frow, row0 + 4 * (tid & 3), B)) = v;   // fragment-major
-            }
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps)
+                if (write_saT && has_s[ps]) {
+                    float4 v;
+                    v.x = lds[ms[ps][0]]; v.y = lds[ms[ps][1]]; v.z = lds[ms[ps][2]]; v.w = lds[ms[ps][3]];
+                    const int f = (tid + 256 * ps) >> 2, frow = (f < O) ? f : L.KA + (f - O);
+                    *reinterpret_cast<float4 *>(S + L.off_saT + frag_off(frow, row0 + 4 * (tid & 3), B)) = v;   // fragment-major
+                }
             lds_barrier();                         // tile free for the next block
             return;
         }
@@ -289,9 +296,11 @@ int ensure_stage(sac_buffer *b, size_t bytes) {
     return 0;
 }
 
+// Index and slot buffers only ever grow: a loop of 20 steps behind one of 2000 (or the other way round) must not
+// pay hipFree + hipMalloc + a memset inside its call (rlkit_custom.py:233-240 runs this loop once per epoch).
 int ensure_idx(sac_buffer *b, int64_t n) {
     if (b->idx_cap >= n) return 0;
-    if (b->d_idx) SAC_HIP(hipFree(b->d_idx));
+    if (b->d_idx) { SAC_HIP(hipStreamSynchronize(b->stream)); SAC_HIP(hipFree(b->d_idx)); }
     b->d_idx = nullptr;
     b->idx_cap = 0;
     SAC_HIP(hipMalloc(&b->d_idx, sizeof(int64_t) * n));
@@ -304,7 +313,7 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
     SlotLayout L = make_slot_layout(B, b->O, b->A);
     const int64_t need = L.slot_floats * n_slots;
     if (b->slots_cap < need) {
-        if (b->d_slots) SAC_HIP(hipFree(b->d_slots));
+        if (b->d_slots) { SAC_HIP(hipStreamSynchronize(b->stream)); SAC_HIP(hipFree(b->d_slots)); }
         b->d_slots = nullptr;
         b->slots_cap = 0;
         SAC_HIP(hipMalloc(&b->d_slots, sizeof(float) * need));
@@ -312,7 +321,10 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
         SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
         b->slots_cap = need;
     } else if (b->slot.Bt != B) {
-        SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * need, b->stream));
+        // another batch size = another layout: EVERY slot of the allocation may hold rows of the old one where the
+        // new one has padding, so the whole allocation is cleared (not just the slots this call asks for)
+        SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * b->slots_cap, b->stream));
+        if (b->d_idx) SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * b->idx_cap, b->stream));
     }
     b->slot = L;
     b->n_slots = n_slots;
@@ -369,23 +381,37 @@ int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batc
 
 using namespace sac;
 
-// one contiguous ring segment [at, at+n) <- staged rows
+// one contiguous ring segment [at, at+n) <- staged rows.
+// Asynchronous ingest (the reference inserts the 2 500 exploration steps of an epoch between rollouts and training,
+// /root/reference/util/rlkit_custom.py:223-231): rows are packed into one of TWO pinned staging buffers and handed to
+// the copy engine with hipMemcpyAsync on the buffer's stream; the call returns as soon as the copies are ENQUEUED.
+// While the DMA of one staging buffer runs, the host packs the next chunk into the other one (or goes back to
+// stepping environments).  Everything that reads the storage (index draw + gather, sac_buffer_read) runs on the same
+// in-order stream, so it sees the inserted rows without any host-side wait; a staging buffer is reused only after the
+// event recorded behind its copies has fired.  The caller's arrays are free for reuse when the call returns (they
+// have been copied into pinned memory by then).
 template <typename Src>
 static int add_segment(sac_buffer *b, int64_t at, int64_t n, const Src *obs, const Src *act, const Src *rew,
                        const Src *nobs, const uint8_t *term) {
     const int O = b->O, A = b->A, Ost = b->Ost, Ast = b->Ast;
-    const int64_t CH = 16384;
+    const int64_t CH = sac_buffer::INGEST_ROWS;
     const size_t per_row = sizeof(float) * (size_t)(2 * Ost + Ast + 2);
-    if (ensure_stage(b, per_row * CH)) return -1;
+    for (int k = 0; k < 2; ++k)
+        if (!b->h_ing[k]) {
+            SAC_HIP(hipHostMalloc(&b->h_ing[k], per_row * CH, hipHostMallocDefault));
+            SAC_HIP(hipEventCreateWithFlags(&b->ing_free[k], hipEventDisableTiming));
+        }
     for (int64_t done = 0; done < n; done += CH) {
         const int64_t m = (n - done < CH) ? n - done : CH;
-        float *so = (float *)b->h_stage, *sn = so + m * Ost, *sa = sn + m * Ost, *sr = sa + m * Ast, *st = sr + m;
+        const int k = (int)(b->ing_next++ & 1);
+        if (b->ing_busy[k]) { SAC_HIP(hipEventSynchronize(b->ing_free[k])); b->ing_busy[k] = false; }
+        float *so = (float *)b->h_ing[k], *sn = so + m * Ost, *sa = sn + m * Ost, *sr = sa + m * Ast, *st = sr + m;
         for (int64_t i = 0; i < m; ++i) {
             const Src *po = obs + (done + i) * O, *pn = nobs + (done + i) * O, *pa = act + (done + i) * A;
-            for (int k = 0; k < O; ++k) { so[i * Ost + k] = (float)po[k]; sn[i * Ost + k] = (float)pn[k]; }
-            for (int k = O; k < Ost; ++k) { so[i * Ost + k] = 0.f; sn[i * Ost + k] = 0.f; }
-            for (int k = 0; k < A; ++k) sa[i * Ast + k] = (float)pa[k];
-            for (int k = A; k < Ast; ++k) sa[i * Ast + k] = 0.f;
+            for (int kk = 0; kk < O; ++kk) { so[i * Ost + kk] = (float)po[kk]; sn[i * Ost + kk] = (float)pn[kk]; }
+            for (int kk = O; kk < Ost; ++kk) { so[i * Ost + kk] = 0.f; sn[i * Ost + kk] = 0.f; }
+            for (int kk = 0; kk < A; ++kk) sa[i * Ast + kk] = (float)pa[kk];
+            for (int kk = A; kk < Ast; ++kk) sa[i * Ast + kk] = 0.f;
             sr[i] = (float)rew[done + i];
             st[i] = term[done + i] ? 1.0f : 0.0f;
         }
@@ -395,7 +421,8 @@ static int add_segment(sac_buffer *b, int64_t at, int64_t n, const Src *obs, con
         SAC_HIP(hipMemcpyAsync(b->act + r0 * Ast, sa, sizeof(float) * m * Ast, hipMemcpyHostToDevice, b->stream));
         SAC_HIP(hipMemcpyAsync(b->rew + r0, sr, sizeof(float) * m, hipMemcpyHostToDevice, b->stream));
         SAC_HIP(hipMemcpyAsync(b->term + r0, st, sizeof(float) * m, hipMemcpyHostToDevice, b->stream));
-        SAC_HIP(hipStreamSynchronize(b->stream));   // staging buffer is reused
+        SAC_HIP(hipEventRecord(b->ing_free[k], b->stream));
+        b->ing_busy[k] = true;
     }
     return 0;
 }
@@ -478,6 +505,10 @@ int sac_buffer_destroy(sac_buffer_t *b) {
                     (void *)b->d_rng, (void *)b->d_idx, (void *)b->d_slots})
         (void)hipFree(p);
     if (b->h_stage) (void)hipHostFree(b->h_stage);
+    for (int k = 0; k < 2; ++k) {
+        if (b->h_ing[k]) (void)hipHostFree(b->h_ing[k]);
+        if (b->ing_free[k]) (void)hipEventDestroy(b->ing_free[k]);
+    }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_ring_idx);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_ready) if (e) (void)hipEventDestroy(e);
@@ -498,6 +529,29 @@ int sac_buffer_add(sac_buffer_t *b, int64_t n, const float *obs, const float *ac
 int sac_buffer_add_f64(sac_buffer_t *b, int64_t n, const double *obs, const double *act, const double *rew,
                        const double *next_obs, const uint8_t *term) {
     return add_impl<double>(b, n, obs, act, rew, next_obs, term);
+}
+
+// 1 while inserted rows are still on their way to HBM, 0 once every enqueued insert has landed (never blocks)
+int sac_buffer_ingest_pending(sac_buffer_t *b) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    for (int k = 0; k < 2; ++k)
+        if (b->ing_busy[k]) {
+            const hipError_t e = hipEventQuery(b->ing_free[k]);
+            if (e == hipErrorNotReady) return 1;
+            if (e != hipSuccess) { sac::set_error("hipEventQuery failed: %s", hipGetErrorString(e)); return -1; }
+            b->ing_busy[k] = false;
+        }
+    return 0;
+}
+
+// block until every enqueued insert has landed (nobody has to call this: readers are ordered behind the inserts on
+// the buffer's stream; it exists for measurements and for callers that want the PCIe transfer done at a known point)
+int sac_buffer_ingest_wait(sac_buffer_t *b) {
+    SAC_REQUIRE(b != nullptr, "null buffer");
+    SAC_HIP(hipSetDevice(b->device));
+    for (int k = 0; k < 2; ++k)
+        if (b->ing_busy[k]) { SAC_HIP(hipEventSynchronize(b->ing_free[k])); b->ing_busy[k] = false; }
+    return 0;
 }
 
 // Storage rows [start, start + n) -> dense host arrays (checkpointing; the reference's buffer is plain
@@ -531,6 +585,12 @@ int sac_buffer_set_cursor(sac_buffer_t *b, int64_t top, int64_t size) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_REQUIRE(top >= 0 && top < b->capacity && size >= 0 && size <= b->capacity, "bad cursor (top %lld, size %lld)",
                 (long long)top, (long long)size);
+    if (size < b->size) {      // pad entries of the index buffers must stay valid rows: back to row 0
+        SAC_HIP(hipSetDevice(b->device));
+        if (b->d_idx) SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * b->idx_cap, b->stream));
+        if (b->d_ring_idx)
+            SAC_HIP(hipMemsetAsync(b->d_ring_idx, 0, sizeof(int64_t) * (size_t)b->ring_layout.B * sac_buffer::NRING, b->stream));
+    }
     b->top = top; b->size = size;
     return 0;
 }

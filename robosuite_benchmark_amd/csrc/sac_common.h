@@ -108,8 +108,13 @@ struct sac_buffer {
     float *d_slots = nullptr; int64_t slots_cap = 0;      // floats
     sac::SlotLayout slot{};
     int64_t n_slots = 0;
-    // pinned staging
+    // pinned staging (read-out); double-buffered pinned staging of the asynchronous ingest (sac_buffer_add*)
     void *h_stage = nullptr; size_t stage_bytes = 0;
+    static constexpr int64_t INGEST_ROWS = 8192;     // rows per staging buffer
+    void *h_ing[2] = {nullptr, nullptr};
+    hipEvent_t ing_free[2] = {nullptr, nullptr};     // recorded behind the copies that read staging buffer k
+    bool ing_busy[2] = {false, false};
+    uint64_t ing_next = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // device-resident batches of the stepwise interface (sac_random_batch_device): a ring of NRING slots; batch
     // number n lives in slot n % NRING until batch n + NRING is drawn

@@ -1530,7 +1530,9 @@ struct sac_trainer {
     Ctl *d_ctl = nullptr;
     void *h_stage = nullptr; size_t stage_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // slot double buffer
+    static constexpr int NLOOP_EV = 8;
+    hipEvent_t ev_ready[NLOOP_EV] = {}, ev_done[NLOOP_EV] = {};                      // chunks of sac_train_loop in flight
+    float *h_diag = nullptr;                          // pinned: first[32] | last[32] of a loop
     float last_ms[4] = {0, 0, 0, 0};
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
@@ -1767,6 +1769,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SAC_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_diag), sizeof(float) * 2 * SAC_DIAG_N, hipHostMallocDefault));
     hipStream_t s = t->stream;
     const int B = t->B;
 
@@ -1931,6 +1934,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipFree(t->arena);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
+    if (t->h_diag) (void)hipHostFree(t->h_diag);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_done) if (e) (void)hipEventDestroy(e);
@@ -2109,6 +2113,16 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     return 0;
 }
 
+// Slots of a loop live in a ring of LOOP_RING minibatch slots that is allocated ONCE (first use; never resized with
+// n_steps: a 20-step call behind a 2000-step one must not free / allocate / clear inside the call).  The loop is cut
+// into chunks -- 16, 48, 192, then 256 steps each -- laid out back to back in the ring: while the trainer's stream
+// runs the steps of chunk c, the buffer's stream draws the indices of chunk c+1 (one serial wave) and gathers its
+// slots; the short first chunks let step 0 start behind a 16-step draw + gather instead of a 256-step one.  The
+// index stream is one in-order sequence on the buffer's stream, so it consumes NumPy's generator exactly like
+// n_steps random_batch calls.
+constexpr int64_t LOOP_CH = 256, LOOP_RING = 2 * LOOP_CH;
+static inline int64_t loop_chunk_len(int64_t done) { return done == 0 ? 16 : (done == 16 ? 48 : (done == 64 ? 192 : LOOP_CH)); }
+
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
     SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");
@@ -2117,37 +2131,48 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    // Chunks of CH steps, slots double-buffered: while the trainer's stream runs the steps of chunk
-    // c, the buffer's stream draws the indices of chunk c+1 (one serial wave) and gathers its slots.
-    // The index stream is one in-order sequence on the buffer's stream, so it consumes NumPy's
-    // generator exactly like n_steps random_batch calls.
-    const int64_t CH = 256;
-    const int64_t n_chunks = (n_steps + CH - 1) / CH;
-    const int64_t n_slots = n_steps < 2 * CH ? n_steps : 2 * CH;
-    if (ensure_slots(b, t->Bt, n_slots)) return -1;
-    if (ensure_idx(b, n_slots * t->B)) return -1;
+    if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
+    if (ensure_idx(b, LOOP_RING * t->B)) return -1;
+    struct Live { int64_t pos, m; int ev; };
+    Live live[sac_trainer::NLOOP_EV];
+    int n_live = 0;
     SAC_HIP(hipEventRecord(t->ev[0], s));
-    for (int64_t c = 0; c < n_chunks; ++c) {
-        const int64_t first = c * CH, m = (n_steps - first < CH) ? n_steps - first : CH;
-        const int half = (int)(c & 1);
-        const int64_t slot0 = (n_chunks == 1) ? 0 : half * CH;
-        if (c >= 2) SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[half], 0));   // trainer is done with this half
+    int64_t done = 0, pos = 0;
+    for (int c = 0; done < n_steps; ++c) {
+        const int64_t first = done, want = loop_chunk_len(done), m = (n_steps - first < want) ? n_steps - first : want;
+        if (pos + m > LOOP_RING) pos = 0;
+        const int e = c % sac_trainer::NLOOP_EV;
+        // chunks that still own some of these slots: the trainer must be done with them
+        for (int i = 0; i < n_live;) {
+            if (live[i].pos < pos + m && pos < live[i].pos + live[i].m) {
+                SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[live[i].ev], 0));
+                live[i] = live[--n_live];
+            } else ++i;
+        }
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[0], b->stream));
-        if (launch_sample(b, t->Bt, m, slot0 * t->B)) return -1;
+        if (launch_sample(b, t->Bt, m, pos * t->B)) return -1;
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[1], b->stream));
-        if (launch_gather(b, b->d_idx + slot0 * t->B, t->B, m, b->d_slots + (size_t)slot0 * b->slot.slot_floats, b->slot, 1))
+        if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1))
             return -1;
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[2], b->stream));
-        SAC_HIP(hipEventRecord(t->ev_ready[half], b->stream));
-        SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[half], 0));
+        SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
+        SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0));
         for (int64_t i = 0; i < m; ++i)
-            if (launch_step(t, b->d_slots + (size_t)(slot0 + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
-        SAC_HIP(hipEventRecord(t->ev_done[half], s));
+            if (launch_step(t, b->d_slots + (size_t)(pos + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
+        SAC_HIP(hipEventRecord(t->ev_done[e], s));
+        SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV, "internal: loop chunk bookkeeping overflow");
+        live[n_live++] = Live{pos, m, e};
+        pos += m;
+        done += m;
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
-    if (diag_first) SAC_HIP(hipMemcpyAsync(diag_first, t->dev.diag_first, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
-    if (diag_last) SAC_HIP(hipMemcpyAsync(diag_last, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
+    // first[32] | last[32] are adjacent on the device: one copy into pinned memory (a copy into the caller's pageable
+    // arrays would be staged by the runtime, twice)
+    if (diag_first || diag_last)
+        SAC_HIP(hipMemcpyAsync(t->h_diag, t->dev.diag_first, sizeof(float) * 2 * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
+    if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
+    if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     SAC_HIP(hipEventElapsedTime(&t->last_ms[1], b->ev[0], b->ev[1]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[2], b->ev[1], b->ev[2]));
     SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));

@@ -16,7 +16,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from .checkpoint import load_checkpoint, save_checkpoint
+from .checkpoint import checkpoint_exists, load_checkpoint, save_checkpoint
 from .networks import (FlattenMlp, GaussianStrategy, MakeDeterministic, PolicyWrappedWithExplorationStrategy,
                        TanhGaussianPolicy, TanhMlpPolicy)
 from .replay_buffer import EnvReplayBuffer
@@ -159,7 +159,7 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
     writer, fh = None, None
     first_epoch = 0
     host_rngs = dict(policy_noise=policy._noise, expl_env=expl_env._rs, eval_env=eval_env._rs)
-    if resume and checkpoint_dir and os.path.exists(os.path.join(checkpoint_dir, "manifest.json")):
+    if resume and checkpoint_dir and checkpoint_exists(checkpoint_dir):
         extra = load_checkpoint(checkpoint_dir, trainer, buf)
         first_epoch = int(extra["epoch"]) + 1
         _rs_unpack(np.random, extra["np_random"])

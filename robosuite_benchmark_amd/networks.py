@@ -14,7 +14,10 @@ import numpy as np
 
 
 class _Mlp:
-    def __init__(self, hidden_sizes, output_sizes, input_size, init_w, rs=None):
+    def __init__(self, hidden_sizes, output_sizes, input_size, init_w, rs=None, b_init_value=0.1):
+        # b_init_value: rlkit Mlp's constant hidden bias -- 0.1 at the commit the reference pins (b7f97b2,
+        # /root/reference/README.md:28; later rlkit: 0).  Unpinned: rlkit is not vendored and no shipped artefact
+        # holds an initial bias; it only shapes from-scratch learning curves, never per-step parity.
         rs = rs or np.random      # rlkit draws its init from the torch global generator; [R]
         self.input_size, self.hidden_sizes = int(input_size), list(hidden_sizes)
         self.layers = OrderedDict()
@@ -22,7 +25,7 @@ class _Mlp:
         for i, h in enumerate(self.hidden_sizes):
             bound = 1.0 / math.sqrt(h)      # rlkit fanin_init: size[0] of the (out,in) weight  [R]
             self.layers[f"fc{i}"] = [rs.uniform(-bound, bound, (h, d)).astype(np.float32),
-                                     np.zeros(h, np.float32)]
+                                     np.full(h, b_init_value, np.float32)]
             d = h
         for name, n_out in output_sizes:
             self.layers[name] = [rs.uniform(-init_w, init_w, (n_out, d)).astype(np.float32),
@@ -63,7 +66,8 @@ class FlattenMlp(_Mlp):
     """``FlattenMlp(input_size=, output_size=, hidden_sizes=)``: cat(inputs, dim=1) -> relu MLP."""
 
     def __init__(self, hidden_sizes, output_size, input_size, init_w=3e-3, **kwargs):
-        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"))
+        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"),
+                         kwargs.get("b_init_value", 0.1))
 
     def forward_np(self, *inputs):
         h = np.concatenate(inputs, axis=1).astype(np.float32)
@@ -85,7 +89,7 @@ class TanhGaussianPolicy(_Mlp):
     def __init__(self, hidden_sizes, obs_dim, action_dim, std=None, init_w=1e-3, **kwargs):
         assert std is None, "fixed-std policies are not used by the benchmark"
         super().__init__(hidden_sizes, [("last_fc", action_dim), ("last_fc_log_std", action_dim)], obs_dim,
-                         init_w, kwargs.get("rs"))
+                         init_w, kwargs.get("rs"), kwargs.get("b_init_value", 0.1))
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self._noise = np.random.RandomState(0)
 
@@ -99,12 +103,16 @@ class TanhGaussianPolicy(_Mlp):
         return h @ wm.T + bm, np.clip(h @ ws.T + bs, self.LOG_SIG_MIN, self.LOG_SIG_MAX)
 
     def get_actions(self, obs_np, deterministic=False):
-        if self._trainer is not None:
-            self._trainer.refresh_host_policy()
-        mean, log_std = self._trunk(obs_np)
+        obs = np.ascontiguousarray(np.atleast_2d(obs_np), dtype=np.float32)
+        eps = None if deterministic else self._noise.standard_normal((obs.shape[0], self.action_dim)).astype(np.float32)
+        tr = self._trainer
+        if tr is not None and getattr(tr, "_h", None) is not None:
+            # the library's acting entry (sac_policy_act: host forward from the policy mirrored D2H once per
+            # training block) -- ONE implementation of the acting path once a trainer owns the weights
+            return tr.policy_act(obs, deterministic, eps)
+        mean, log_std = self._trunk(obs)           # holder without a trainer (no device state yet)
         if deterministic:
             return np.tanh(mean)
-        eps = self._noise.standard_normal(mean.shape).astype(np.float32)
         return np.tanh(mean + np.exp(log_std) * eps)
 
     def get_action(self, obs_np, deterministic=False):
@@ -138,13 +146,16 @@ class TanhMlpPolicy(_Mlp):
     target): relu MLP with a tanh output; ``get_action(obs_np)`` returns ``(action, {})``."""
 
     def __init__(self, hidden_sizes, output_size, input_size, init_w=1e-3, **kwargs):
-        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"))
+        super().__init__(hidden_sizes, [("last_fc", output_size)], input_size, init_w, kwargs.get("rs"),
+                         kwargs.get("b_init_value", 0.1))
         self.obs_dim, self.action_dim = int(input_size), int(output_size)
 
     def get_actions(self, obs_np):
-        if self._trainer is not None:
-            self._trainer.refresh_host_policy()
-        h = np.asarray(obs_np, np.float32)
+        obs = np.ascontiguousarray(np.atleast_2d(obs_np), dtype=np.float32)
+        tr = self._trainer
+        if tr is not None and getattr(tr, "_h", None) is not None:
+            return tr.policy_act(obs, True, None)  # sac_policy_act (TD3 handles: tanh(last_fc))
+        h = obs
         names = list(self.layers)
         for n in names[:-1]:
             w, b = self.layers[n]

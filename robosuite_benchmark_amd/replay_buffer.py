@@ -144,6 +144,14 @@ class EnvReplayBuffer:
         _lib.check(fn(self._h, n, _lib.ptr(o), _lib.ptr(a), _lib.ptr(r), _lib.ptr(no), _lib.ptr(t)),
                    "sac_buffer_add")
 
+    def ingest_pending(self):
+        """True while inserted rows are still on their way to HBM (inserts are asynchronous: add_* returns once the
+        rows sit in pinned staging and their copies are enqueued; sampling is ordered behind them on the device)."""
+        return bool(_lib.check(self._lib.sac_buffer_ingest_pending(self._h), "sac_buffer_ingest_pending"))
+
+    def ingest_wait(self):
+        _lib.check(self._lib.sac_buffer_ingest_wait(self._h), "sac_buffer_ingest_wait")
+
     def add_path(self, path):
         self.add_block(path["observations"], path["actions"], path["rewards"], path["next_observations"],
                        path["terminals"])

@@ -195,6 +195,19 @@ class SACTrainer:
     def end_epoch(self, epoch):
         self._need_to_update_eval_statistics = True
 
+    def policy_act(self, obs, deterministic, eps):
+        """policy.get_actions through the C ABI: sac_policy_act per observation row (rlkit_custom.py:437 acts on one
+        observation at a time).  The library mirrors the policy D2H on the first call after a training block."""
+        obs = _lib.f32(obs)
+        n, A = obs.shape[0], self.act_dim
+        out = np.empty((n, A), np.float32)
+        e = None if eps is None else _lib.f32(eps)
+        for i in range(n):
+            _lib.check(self._lib.sac_policy_act(self._h, obs[i].ctypes.data_as(C.c_void_p), int(bool(deterministic)),
+                                                None if e is None else e[i].ctypes.data_as(C.c_void_p),
+                                                out[i].ctypes.data_as(C.c_void_p)), "sac_policy_act")
+        return out
+
     def refresh_host_policy(self):
         """Mirror the trained policy D2H once per training block (acting stays on the host)."""
         if self._h is not None and self._host_policy_stale:

@@ -9,15 +9,56 @@ from __future__ import annotations
 
 import json
 
-# (env_name, n_robots) -> obs_dim for OSC_POSE-family runs with use_object_obs=True, no cameras
+# Every (env_name, robots, controller) the reference ships a run or a training config for -> (obs_dim, action_dim),
+# read off the tensor shapes inside its params.pkl snapshots (policy fc0 / last_fc, qf fc0) by
+# tests/golden/make_dims_fixture.py -> tests/golden/env_dims.json (pickletools walk, nothing unpickled).
+# LiftModded (the fork's env, /root/reference/training_configs/*) adds object / goal features: 64 with the Jaco arm.
+PINNED_DIMS = {
+    ("Door", ('Panda',), "JOINT_VELOCITY"): (46, 8),
+    ("Door", ('Panda',), "OSC_POSE"): (46, 7),
+    ("Door", ('Sawyer',), "JOINT_VELOCITY"): (46, 8),
+    ("Door", ('Sawyer',), "OSC_POSE"): (46, 7),
+    ("LiftModded", ('Jaco',), "OSC_POSITION"): (64, 4),
+    ("Lift", ('Jaco',), "OSC_POSITION"): (50, 4),
+    ("Lift", ('Panda',), "JOINT_VELOCITY"): (42, 8),
+    ("Lift", ('Panda',), "OSC_POSE"): (42, 7),
+    ("Lift", ('Sawyer',), "JOINT_VELOCITY"): (42, 8),
+    ("Lift", ('Sawyer',), "OSC_POSE"): (42, 7),
+    ("NutAssemblyRound", ('Panda',), "OSC_POSE"): (46, 7),
+    ("NutAssemblyRound", ('Sawyer',), "OSC_POSE"): (46, 7),
+    ("PickPlaceCan", ('Panda',), "OSC_POSE"): (46, 7),
+    ("PickPlaceCan", ('Sawyer',), "OSC_POSE"): (46, 7),
+    ("PickPlaceMilk", ('Panda',), "OSC_POSE"): (46, 7),
+    ("PickPlaceMilk", ('Sawyer',), "OSC_POSE"): (46, 7),
+    ("Stack", ('Panda',), "JOINT_VELOCITY"): (55, 8),
+    ("Stack", ('Panda',), "OSC_POSE"): (55, 7),
+    ("Stack", ('Sawyer',), "JOINT_VELOCITY"): (55, 8),
+    ("Stack", ('Sawyer',), "OSC_POSE"): (55, 7),
+    ("TwoArmHandoff", ('Panda', 'Panda'), "OSC_POSE"): (86, 14),
+    ("TwoArmHandoff", ('Sawyer', 'Sawyer'), "OSC_POSE"): (86, 14),
+    ("TwoArmLift", ('Panda', 'Panda'), "OSC_POSE"): (89, 14),
+    ("TwoArmLift", ('Sawyer', 'Sawyer'), "OSC_POSE"): (89, 14),
+    ("TwoArmPegInHole", ('Panda', 'Panda'), "OSC_POSE"): (73, 12),
+    ("TwoArmPegInHole", ('Panda', 'Sawyer'), "OSC_POSE"): (73, 12),
+    ("TwoArmPegInHole", ('Sawyer', 'Sawyer'), "OSC_POSE"): (73, 12),
+    ("Wipe", ('Panda',), "JOINT_VELOCITY"): (379, 7),
+    ("Wipe", ('Panda',), "OSC_POSE"): (379, 6),
+    ("Wipe", ('Sawyer',), "JOINT_VELOCITY"): (379, 7),
+    ("Wipe", ('Sawyer',), "OSC_POSE"): (379, 6),
+}
+# the rule behind the table, for combinations of known tasks nobody shipped a run for (Panda / Sawyer arms observe
+# alike; the Jaco's three-finger gripper adds proprioception, so it is only served from the pinned table):
+# (env_name, n_robots) -> obs_dim for runs with use_object_obs=True, no cameras
 OBS_DIMS = {
     ("Lift", 1): 42, ("Door", 1): 46, ("PickPlaceCan", 1): 46, ("PickPlaceMilk", 1): 46,
     ("NutAssemblyRound", 1): 46, ("Stack", 1): 55, ("Wipe", 1): 379,
     ("TwoArmPegInHole", 2): 73, ("TwoArmHandoff", 2): 86, ("TwoArmLift", 2): 89,
 }
-# controller -> action dims per arm (gripper included); Wipe has no gripper (one fewer)
+# controller -> action dims per arm (gripper included); Wipe and TwoArmPegInHole run without grippers (one fewer)
+NO_GRIPPER = ("Wipe", "TwoArmPegInHole")
 ACT_PER_ARM = {"OSC_POSE": 7, "OSC_POSITION": 4, "JOINT_VELOCITY": 8, "JOINT_TORQUE": 8, "JOINT_POSITION": 8,
                "IK_POSE": 7}
+RULE_ROBOTS = ("Panda", "Sawyer")
 
 
 def load_variant(path):
@@ -52,13 +93,18 @@ def env_dims(env_kwargs, obs_dim=None, action_dim=None):
     """(obs_dim, action_dim) the reference would read from the robosuite env (rlkit_utils.py:61-62)."""
     if obs_dim is not None and action_dim is not None:
         return int(obs_dim), int(action_dim)
+    # (keys the table does not use -- horizon, control_freq, reward_scale, hard_reset, ignore_done, the fork's
+    #  `weights` of LiftModded ... -- belong to the env constructor and pass through untouched)
     name, robots = env_kwargs["env_name"], env_kwargs["robots"]
     robots = [robots] if isinstance(robots, str) else list(robots)
     ctrl = env_kwargs.get("controller", "OSC_POSE")
+    pinned = PINNED_DIMS.get((name, tuple(robots), ctrl))
+    if pinned is not None:
+        return pinned
     key = (name, len(robots))
-    if key not in OBS_DIMS or ctrl not in ACT_PER_ARM:
-        raise KeyError(f"no pinned dims for env {name!r} x{len(robots)} / controller {ctrl!r}: pass obs_dim/action_dim")
-    per_arm = ACT_PER_ARM[ctrl] - (1 if name == "Wipe" else 0)
+    if key not in OBS_DIMS or ctrl not in ACT_PER_ARM or any(r not in RULE_ROBOTS for r in robots):
+        raise KeyError(f"no pinned dims for env {name!r} x {robots!r} / controller {ctrl!r}: pass obs_dim/action_dim")
+    per_arm = ACT_PER_ARM[ctrl] - (1 if name in NO_GRIPPER else 0)
     return OBS_DIMS[key], per_arm * len(robots)
 
 

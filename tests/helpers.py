@@ -4,7 +4,8 @@ import numpy as np
 from oracle.sac_step_torch import RlkitEquivalentSAC, init_sac_params
 
 TASK_DIMS = {"Lift": (42, 7), "Door": (46, 7), "Stack": (55, 7), "TwoArmLift": (89, 14), "Wipe": (379, 6),
-             "TwoArmPegInHole": (73, 12), "TwoArmHandoff": (86, 14)}
+             "TwoArmPegInHole": (73, 12), "TwoArmHandoff": (86, 14), "PickPlaceCan": (46, 7),
+             "NutAssemblyRound": (46, 7), "LiftModded": (64, 4), "LiftJaco": (50, 4), "WipeJV": (379, 7)}
 
 
 def synth_transitions(n, O, A, seed=1234, term_frac=0.0, reward_scale=1.0):

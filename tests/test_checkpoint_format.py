@@ -67,3 +67,69 @@ def test_raw_read_of_a_shipped_snapshot_matches_the_committed_fixture():
     want = np.load(os.path.join(HERE, "golden", "trained_weights_lift_seed129.npz"))
     for net in ("policy", "qf1", "qf2"):
         np.testing.assert_array_equal(got[net], want[net])
+
+
+# ---- save/load atomicity (no GPU: a stand-in with the trainer's checkpoint surface) -----------------------------
+class _StubTrainer:
+    NETS = {"policy": 0, "qf1": 1, "qf2": 2, "target_qf1": 3, "target_qf2": 4}
+    obs_dim, act_dim, _batch, _num_train_steps = 5, 2, 8, 0
+    discount = reward_scale = policy_lr = qf_lr = soft_target_tau = 0.5
+    target_update_period, use_automatic_entropy_tuning, target_entropy, noise_seed = 1, True, -2.0, 0
+
+    def __init__(self, fill):
+        self._h = object()
+        self.fill(fill)
+
+    def fill(self, v):
+        self.st = dict(params={k: np.full(32, v + i, np.float32) for i, k in enumerate(self.NETS)},
+                       opt={k: (np.full(32, v, np.float32), np.full(32, -v, np.float32)) for k in ("policy", "qf1", "qf2")},
+                       scalars=np.full(6, v, np.float64))
+
+    def state_dict(self):
+        return self.st
+
+    def load_state_dict(self, st):
+        self.st = st
+
+
+def test_a_killed_save_leaves_the_previous_checkpoint_intact(tmp_path, monkeypatch):
+    d = str(tmp_path / "ck")
+    tr = _StubTrainer(1.0)
+    ck.save_checkpoint(d, tr, extra=dict(epoch=0))
+    tr.fill(2.0)
+    real_save, calls = ck._save, []
+
+    def dying_save(dirname, man, name, arr):
+        calls.append(name)
+        if len(calls) == 4:
+            raise KeyboardInterrupt("killed half-way through the second save")
+        real_save(dirname, man, name, arr)
+
+    monkeypatch.setattr(ck, "_save", dying_save)
+    with pytest.raises(KeyboardInterrupt):
+        ck.save_checkpoint(d, tr, extra=dict(epoch=1))
+    monkeypatch.setattr(ck, "_save", real_save)
+    back = _StubTrainer(9.0)
+    assert ck.load_checkpoint(d, back) == dict(epoch=0)          # the old generation, whole
+    assert float(back.st["params"]["policy"][0]) == 1.0 and float(back.st["opt"]["qf2"][1][0]) == -1.0
+    ck.save_checkpoint(d, tr, extra=dict(epoch=1))               # the next complete save cleans the torn one up
+    assert ck.load_checkpoint(d, back) == dict(epoch=1) and float(back.st["params"]["policy"][0]) == 2.0
+    assert sorted(x for x in os.listdir(d) if x.startswith("gen-")) == [os.path.basename(ck.current_dir(d))]
+
+
+def test_truncated_or_swapped_arrays_are_refused(tmp_path):
+    d = str(tmp_path / "ck")
+    ck.save_checkpoint(d, _StubTrainer(1.0), extra=dict(epoch=0))
+    cur = ck.current_dir(d)
+    back = _StubTrainer(9.0)
+    f = os.path.join(cur, "adam_v.qf1.npy")
+    blob = open(f, "rb").read()
+    open(f, "wb").write(blob[:len(blob) // 2])                   # a save that stopped half-way through a file
+    with pytest.raises(Exception):
+        ck.load_checkpoint(d, back)
+    np.save(f, np.full(32, 123.0, np.float32))                   # right dtype and shape, other content
+    with pytest.raises(ValueError, match="content does not match"):
+        ck.load_checkpoint(d, back)
+    assert float(back.st["params"]["policy"][0]) == 9.0          # nothing was loaded
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint(str(tmp_path / "nothing"), back)

@@ -80,12 +80,21 @@ def test_resume_continues_bit_for_bit(tmp_path):
     kc, pc = buf_c.rng_state()
     assert pa == pc and np.array_equal(ka, kc)
     # torn / foreign checkpoints are refused
-    bad = json.load(open(tmp_path / "ck" / "manifest.json"))
+    cur = ck.current_dir(str(tmp_path / "ck"))
+    bad = json.load(open(os.path.join(cur, "manifest.json")))
     bad["format"] = "something else"
     os.makedirs(tmp_path / "bad")
     json.dump(bad, open(tmp_path / "bad" / "manifest.json", "w"))
     with pytest.raises(ValueError, match="not a"):
         ck.load_checkpoint(str(tmp_path / "bad"), tr_c, buf_c)
+    # an array swapped for another save's (same dtype and shape: only the content hash can tell) is refused, and the
+    # live state is untouched by the failed load
+    before = tr_c.state_dict()
+    a = np.load(os.path.join(cur, "adam_m.qf1.npy"))
+    np.save(os.path.join(cur, "adam_m.qf1.npy"), a + 1.0)
+    with pytest.raises(ValueError, match="content does not match"):
+        ck.load_checkpoint(str(tmp_path / "ck"), tr_c, buf_c)
+    _same_state(before, tr_c.state_dict())
 
 
 def test_exported_state_dicts_hold_the_device_weights(tmp_path):

@@ -40,7 +40,12 @@ def scale_err(got, want):
 # row-block counts above), 1 (B >= 528 with an even row-block count)
 CASES = [("Lift", 128, 0.0), ("Lift", 256, 0.0), ("Door", 1024, 0.0), ("TwoArmLift", 256, 0.0),
          ("Lift", 256, 0.05), ("Wipe", 128, 0.0), ("Lift", 16, 0.0), ("Lift", 512, 0.0), ("Lift", 560, 0.0),
-         ("Stack", 48, 0.1)]
+         ("Stack", 48, 0.1),
+         # every (O, A) of the 8-task sweep (BASELINE.json configs[4], parallel.SWEEP) at the sweep's batch sizes, and
+         # the fork's LiftModded-Jaco 64/4 (/root/reference/training_configs/**/variant.json), Lift-Jaco 50/4
+         ("TwoArmPegInHole", 256, 0.0), ("TwoArmHandoff", 256, 0.0), ("Stack", 256, 0.0), ("Wipe", 256, 0.0),
+         ("PickPlaceCan", 128, 0.0), ("NutAssemblyRound", 128, 0.0), ("LiftModded", 128, 0.0), ("LiftJaco", 128, 0.05),
+         ("Door", 256, 0.0), ("WipeJV", 128, 0.0)]
 
 
 @pytest.mark.parametrize("task,B,term_frac", CASES)
@@ -93,6 +98,67 @@ def test_ten_steps_track_the_oracle():
         check_diag(diag, want, tol=1e-4 if s else TOL)
     sc = hip.state_dict()["scalars"]
     assert sc[3] == 10 and sc[4] == 10
+
+
+def _flat_state(torch_opt, net, key):
+    """torch.optim.Adam state of one oracle net as a flat nn.Linear vector (W, b per layer)."""
+    return np.concatenate([np.concatenate([torch_opt.state[w][key].numpy().ravel(), torch_opt.state[b][key].numpy().ravel()])
+                           for w, b in zip(net.ws, net.bs)])
+
+
+def _adam_f32(p, m, v, g, lr, t):
+    """torch.optim.Adam (fp32 tensors, double bias corrections) restated in NumPy float32."""
+    f = np.float32
+    m = m + f(1.0 - 0.9) * (g - m)                                  # exp_avg.lerp_(grad, 1 - beta1)
+    v = v * f(0.999) + f(1.0 - 0.999) * g * g                       # mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    bc1, bc2s = 1.0 - 0.9 ** t, np.sqrt(1.0 - 0.999 ** t)
+    denom = np.sqrt(v) / f(bc2s) + f(1e-8)
+    p = p + (f(-(lr / bc1)) * m) / denom                            # addcdiv_(exp_avg, denom, value=-step_size)
+    return p.astype(f), m.astype(f), v.astype(f)
+
+
+@pytest.mark.parametrize("task,B", [("Lift", 256), ("TwoArmHandoff", 64)])
+def test_adam_moments_and_update_arithmetic(task, B):
+    """(a) exp_avg / exp_avg_sq of the three trained nets and of log_alpha against torch.optim.Adam's own state after
+    steps 1, 2 and 3, at 5e-5 of each tensor's scale (moments are linear / quadratic in g: no sign ambiguity);
+    (b) the update arithmetic -- bias corrections, beta accumulation at step >= 2, eps placement -- bit-level: the
+    parameters after every step equal a float32 NumPy restatement of torch's Adam applied to the HIP path's OWN
+    gradients (so gradient noise, which decides the sign of m/sqrt(v) where g ~ 0, does not enter)."""
+    O, A = TASK_DIMS[task]
+    oracle, hip = make_pair(O, A, B, seed=13)
+    nets = {"policy": (oracle.policy, oracle.policy_opt, 1e-3), "qf1": (oracle.qf1, oracle.qf1_opt, 5e-4),
+            "qf2": (oracle.qf2, oracle.qf2_opt, 5e-4)}
+    st = hip.state_dict()
+    ref = {k: (st["params"][k].copy(), np.zeros_like(st["params"][k]), np.zeros_like(st["params"][k])) for k in nets}
+    for step in (1, 2, 3):
+        np_batch, eps = batch_and_noise(B, O, A, seed=300 + step)
+        oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"], np_batch["terminals"],
+                    np_batch["next_observations"], *eps)
+        hip.train(np_batch, eps=eps)
+        st = hip.state_dict()
+        for name, (net, opt, lr) in nets.items():
+            m_hip, v_hip = st["opt"][name]
+            assert scale_err(m_hip, _flat_state(opt, net, "exp_avg")) < 5e-5, (name, step, "exp_avg")
+            assert scale_err(v_hip, _flat_state(opt, net, "exp_avg_sq")) < 5e-5, (name, step, "exp_avg_sq")
+            g = hip.debug_fetch("g_" + name, m_hip.size)
+            ref[name] = _adam_f32(*ref[name], g, lr, step)
+            p_ref, m_ref, v_ref = ref[name]
+            assert np.max(np.abs(st["params"][name] - p_ref)) <= 1e-7, (name, step, "params vs restated Adam")
+            assert np.max(np.abs(m_hip - m_ref)) <= 1e-9 + 1e-6 * np.max(np.abs(m_ref)), (name, step)
+            assert np.max(np.abs(v_hip - v_ref)) <= 1e-12 + 1e-6 * np.max(np.abs(v_ref)), (name, step)
+        a_st = oracle.alpha_opt.state[oracle.log_alpha]
+        sc = st["scalars"]                          # log_alpha, its exp_avg, exp_avg_sq, adam_t, n_steps, alpha
+        assert abs(sc[0] - float(oracle.log_alpha)) <= 1e-6 * max(1.0, abs(float(oracle.log_alpha)))
+        assert abs(sc[1] - float(a_st["exp_avg"])) <= 1e-5 * abs(float(a_st["exp_avg"])) + 1e-9
+        assert abs(sc[2] - float(a_st["exp_avg_sq"])) <= 1e-5 * abs(float(a_st["exp_avg_sq"])) + 1e-12
+        assert sc[3] == step
+    # where the gradient is well above its own noise the parameters agree with the oracle's after three steps
+    after = oracle.export_nets()
+    for name, (net, opt, lr) in nets.items():
+        v_ref = _flat_state(opt, net, "exp_avg_sq")
+        strong = np.sqrt(v_ref) > 1e-2 * np.sqrt(np.max(v_ref))
+        d = np.abs(st["params"][name] - flat_of(after[name]))
+        assert strong.sum() > 100 and np.max(d[strong]) <= 0.02 * lr, (name, float(np.max(d[strong])))
 
 
 def test_known_answers_on_device():

@@ -18,8 +18,12 @@ def filled_buffer(n, O, A, seed):
     return buf
 
 
-# 600 steps: three chunks of the double-buffered slot ring (chunk 2 reuses chunk 0's half)
-@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 128, 25), (42, 7, 256, 12), (89, 14, 256, 6), (10, 3, 32, 600)])
+# 600 / 1100 steps: the chunks 16, 48, 192, 256, 256 ... of the slot ring wrap around it (the fifth chunk reuses the
+# first four's slots).  (60, 7) and (64, 8): observation rows of <= 64 floats (one gather pass per thread) with more
+# than 64 features in cat(obs, act) -- the feature-major copy then needs its second pass.
+@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 128, 25), (42, 7, 256, 12), (89, 14, 256, 6), (10, 3, 32, 600),
+                                         (60, 7, 64, 9), (64, 8, 80, 7), (64, 16, 48, 5), (10, 3, 48, 1100),
+                                         (42, 7, 256, 17), (42, 7, 256, 70)])
 def test_fused_loop_equals_stepwise_interface(O, A, B, steps):
     n = 10_000
     _, fused = make_pair(O, A, B, seed=4, noise_seed=77)
@@ -62,3 +66,22 @@ def test_loop_learns_and_counters_advance():
     assert sc[3] == 200 and sc[4] == 200
     t = hip.loop_timing_ms()
     assert t["steps"] > 0 and t["gather"] > 0
+
+
+def test_loop_lengths_do_not_disturb_each_other():
+    """A long loop, a short one, another batch size and back (the slot ring and the index buffer are allocated once
+    and re-zeroed when the layout changes): every call equals the stepwise interface from the same state."""
+    O, A, n = 42, 7, 6000
+    plan = [(256, 300), (256, 20), (100, 30), (256, 5), (17, 3), (256, 40)]
+    bufs = [filled_buffer(n, O, A, 8), filled_buffer(n, O, A, 8)]
+    for b in bufs:
+        b.seed(5)
+    _, fused = make_pair(O, A, 256, seed=4, noise_seed=3)
+    _, stepw = make_pair(O, A, 256, seed=4, noise_seed=3)
+    for B, steps in plan:
+        first, last = fused.train_loop(bufs[0], steps, batch_size=B)
+        d = [stepw.train(bufs[1].random_batch(B, lazy=False)) for _ in range(steps)]
+        assert np.array_equal(first, d[0]) and np.array_equal(last, d[-1]), (B, steps)
+    sa, sb = fused.state_dict(), stepw.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k

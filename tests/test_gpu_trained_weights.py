@@ -41,25 +41,52 @@ def test_step_parity_on_trained_weights(B, obs_scale):
     assert abs(want["Q1 Predictions Mean"]) > 1.0            # really the large-magnitude regime
 
 
-def test_acting_path_matches_host_policy():
-    """sac_policy_act (C, host forward on mirrored weights) == the numpy holder == tanh(mean) for eval."""
-    import ctypes as C
-    from robosuite_benchmark_amd import _lib
+def test_acting_path_matches_the_oracle_policy():
+    """sac_policy_act (C ABI) and TanhGaussianPolicy.get_action / MakeDeterministic -- which act THROUGH it once a
+    trainer owns the weights -- against oracle.PolicyNet (tanh(mean) for evaluation,
+    tanh(mean + exp(clamp(log_std)) * eps) for exploration) on the trained weights of a shipped run, before and after
+    a training block (the library re-mirrors the policy D2H by itself)."""
+    import torch
+    from robosuite_benchmark_amd import MakeDeterministic, _lib
     O, A, B = 42, 7, 64
-    _, hip = make_pair_from_flat(load_flats(), O, A, B)
+    oracle, hip = make_pair_from_flat(load_flats(), O, A, B)
     lib = _lib.load()
     rs = np.random.RandomState(1)
-    for _ in range(5):
-        o = rs.normal(0, 0.3, O).astype(np.float32)
-        out = np.empty(A, np.float32)
-        _lib.check(lib.sac_policy_act(hip._h, _lib.ptr(o), 1, None, _lib.ptr(out)), "sac_policy_act")
-        want, _ = hip.policy.get_action(o, deterministic=True)
-        assert np.allclose(out, want, atol=2e-5)
-        eps = rs.normal(size=A).astype(np.float32)
-        _lib.check(lib.sac_policy_act(hip._h, _lib.ptr(o), 0, _lib.ptr(eps), _lib.ptr(out)), "sac_policy_act")
-        mean, log_std = hip.policy._trunk(o[None])
-        assert np.allclose(out, np.tanh(mean[0] + np.exp(log_std[0]) * eps), atol=2e-5)
-    assert lib.sac_policy_act(hip._h, _lib.ptr(o), 0, None, _lib.ptr(out)) < 0     # stochastic needs eps
+
+    def check(policy_net):
+        for _ in range(5):
+            o = rs.normal(0, 0.3, O).astype(np.float32)
+            with torch.no_grad():
+                mean, log_std = policy_net.trunk(torch.from_numpy(o[None]))
+            out = np.empty(A, np.float32)
+            _lib.check(lib.sac_policy_act(hip._h, _lib.ptr(o), 1, None, _lib.ptr(out)), "sac_policy_act")
+            assert np.allclose(out, torch.tanh(mean)[0].numpy(), atol=2e-5)
+            eps = rs.normal(size=A).astype(np.float32)
+            _lib.check(lib.sac_policy_act(hip._h, _lib.ptr(o), 0, _lib.ptr(eps), _lib.ptr(out)), "sac_policy_act")
+            want = torch.tanh(mean + torch.exp(log_std) * torch.from_numpy(eps))[0].numpy()
+            assert np.allclose(out, want, atol=2e-5)
+            # the Python duck types: MakeDeterministic(policy).get_action(obs) / policy.get_action(obs)
+            a_det, info = MakeDeterministic(hip.policy).get_action(o)
+            assert info == {} and np.allclose(a_det, torch.tanh(mean)[0].numpy(), atol=2e-5)
+            hip.policy._noise = np.random.RandomState(9)
+            a_sto, _ = hip.policy.get_action(o)
+            e9 = np.random.RandomState(9).standard_normal((1, A)).astype(np.float32)
+            assert np.allclose(a_sto, torch.tanh(mean + torch.exp(log_std) * torch.from_numpy(e9))[0].numpy(), atol=2e-5)
+        assert lib.sac_policy_act(hip._h, _lib.ptr(o), 0, None, _lib.ptr(out)) < 0     # stochastic needs eps
+
+    check(oracle.policy)
+    assert float(oracle.policy.trunk(torch.zeros(1, O))[1].max()) <= 2.0
+    # after a training block acting follows the UPDATED policy (the library re-mirrors it by itself): the oracle's
+    # forward on the parameters the device now holds
+    from oracle.sac_step_torch import PolicyNet
+    from tests.helpers import layers_from_flat
+    obs, act, rew, term, nobs = synth_transitions(B, O, A, seed=12)
+    before = hip.state_dict()["params"]["policy"].copy()
+    for _ in range(3):
+        hip.train(dict(observations=obs, actions=act, rewards=rew, terminals=term.astype(np.float32), next_observations=nobs))
+    now = hip.state_dict()["params"]["policy"]
+    assert not np.array_equal(before, now)
+    check(PolicyNet(layers_from_flat(now, [(256, O), (256, 256), (A, 256), (A, 256)])))
 
 
 def test_two_handles_are_independent():

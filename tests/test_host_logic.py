@@ -43,13 +43,53 @@ def test_get_action_contract():
 
 
 @pytest.mark.parametrize("name,O,A,B", [("Lift-Panda-OSC-POSE-SEED17", 42, 7, 128),
-                                        ("TwoArmLift-PandaPanda-OSC-POSE-SEED17", 89, 14, 128)])
+                                        ("TwoArmLift-PandaPanda-OSC-POSE-SEED17", 89, 14, 128),
+                                        ("LiftModded-Jaco-OSC-POSITION-SEED251", 64, 4, 128),
+                                        ("LiftModded-Jaco-diverse-rewards-2-2-1-0-0", 64, 4, 128)])
 def test_shipped_variant_json_parses_unchanged(name, O, A, B):
     v = variant.validate(variant.load_variant(os.path.join(GOLD, name + ".variant.json")))
     assert variant.env_dims(v["expl_environment_kwargs"]) == (O, A)
     assert v["algorithm_kwargs"]["batch_size"] == B and v["replay_buffer_size"] == 1_000_000
     tk = v["trainer_kwargs"]
     assert (tk["target_update_period"], tk["soft_target_tau"], tk["policy_lr"], tk["qf_lr"]) == (5, 0.005, 1e-3, 5e-4)
+
+
+def test_the_forks_extra_env_kwargs_pass_through():
+    """training_configs/**/variant.json carry `weights` (LiftModded's reward weights): an env-constructor kwarg the
+    dims lookup and the driver must leave alone."""
+    v = variant.validate(variant.load_variant(os.path.join(GOLD, "LiftModded-Jaco-diverse-rewards-2-2-1-0-0.variant.json")))
+    assert len(v["expl_environment_kwargs"]["weights"]) == 5
+    assert variant.env_dims(v["eval_environment_kwargs"]) == (64, 4)
+
+
+def test_pinned_dims_table_equals_the_fixture_read_off_the_shipped_snapshots():
+    fx = json.load(open(os.path.join(GOLD, "env_dims.json")))["dims"]
+    want = {(k.split("|")[0], tuple(k.split("|")[1].split("+")), k.split("|")[2]): tuple(v) for k, v in fx.items()}
+    assert want == variant.PINNED_DIMS and len(want) == 31
+    # the Panda / Sawyer rule reproduces every pinned entry it covers (so unseen combinations follow the same rule)
+    for (env, robots, ctrl), dims in want.items():
+        if all(r in variant.RULE_ROBOTS for r in robots) and (env, len(robots)) in variant.OBS_DIMS:
+            per_arm = variant.ACT_PER_ARM[ctrl] - (1 if env in variant.NO_GRIPPER else 0)
+            assert (variant.OBS_DIMS[(env, len(robots))], per_arm * len(robots)) == dims, (env, robots, ctrl)
+    with pytest.raises(KeyError, match="no pinned dims"):
+        variant.env_dims(dict(env_name="Stack", robots=["Jaco"], controller="OSC_POSE"))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/training_configs"), reason="reference tree not mounted (GPU box)")
+def test_every_shipped_variant_json_parses_unchanged():
+    """All 459 files under /root/reference/{runs,log/runs,training_configs}: schema check + dims for both envs."""
+    import glob
+    files = [f for d in ("runs", "log/runs", "training_configs")
+             for f in glob.glob(f"/root/reference/{d}/**/variant.json", recursive=True)]
+    assert len(files) == 459
+    seen = set()
+    for f in files:
+        v = variant.validate(variant.load_variant(f))
+        d = variant.env_dims(v["expl_environment_kwargs"])
+        assert d == variant.env_dims(v["eval_environment_kwargs"])
+        assert v["policy_kwargs"]["hidden_sizes"] == [256, 256] == v["qf_kwargs"]["hidden_sizes"]
+        seen.add(d)
+    assert (64, 4) in seen and (50, 4) in seen and (379, 7) in seen and (73, 12) in seen
 
 
 def test_default_variant_matches_argparse_defaults_and_dims_table():

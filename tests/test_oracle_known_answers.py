@@ -148,3 +148,46 @@ def test_ka5_buffer_size_progression_in_shipped_rows():
     rows = KA["Lift-Panda-OSC-POSE-SEED17"]["rows"]
     assert [r["replay_buffer/size"] for r in rows[:3]] == [5800, 8300, 10800]
     assert KA["_scan"]["replay_size_max"] == 1_000_000
+
+
+RUN17 = "/root/reference/runs/Lift-Panda-OSC-POSE-SEED17"
+
+
+@pytest.mark.skipif(not os.path.isdir(RUN17), reason="reference tree not mounted (GPU box)")
+def test_embedded_policy_source_holds_the_statements_the_oracle_restates():
+    """The legacy-format params.pkl of a shipped run embeds the SOURCE TEXT of TanhGaussianPolicy / FlattenMlp (torch
+    stores it for its container check).  Walk the pickle with pickletools.genops -- nothing is unpickled, nothing is
+    stored -- and assert the forward() statements oracle.PolicyNet / QNet restate (SURVEY.md 8a a4/a7, App. A lines
+    1-3): the log-std clamp, exp, the reparameterised TanhNormal sample with its pre-tanh value, the summed log-prob,
+    and the concatenating FlattenMlp.  Build-container only."""
+    import glob
+    import io
+    import pickletools
+    path = glob.glob(os.path.join(RUN17, "*", "params.pkl"))[0]
+    data = open(path, "rb").read()
+    texts, pos = [], 0
+    for _ in range(4):                       # magic, protocol, sys info, the object
+        f = io.BytesIO(data[pos:])
+        end = None
+        for op, arg, off in pickletools.genops(f):
+            if op.name in ("BINUNICODE", "SHORT_BINUNICODE", "UNICODE", "BINUNICODE8") and isinstance(arg, str) and "def forward" in arg:
+                texts.append(arg)
+            if op.name == "STOP":
+                end = off + 1
+                break
+        pos += end
+    policy_src = next(t for t in texts if "class TanhGaussianPolicy" in t)
+    mlp_src = next(t for t in texts if "class FlattenMlp" in t)
+    norm = lambda t: " ".join(t.split())     # noqa: E731
+    p = norm(policy_src)
+    assert "log_std = torch.clamp(log_std, LOG_SIG_MIN, LOG_SIG_MAX)" in p
+    assert "std = torch.exp(log_std)" in p
+    assert "tanh_normal = TanhNormal(mean, std)" in p
+    assert "tanh_normal.rsample( return_pretanh_value=True )" in p
+    assert "log_prob = tanh_normal.log_prob( action, pre_tanh_value=pre_tanh_value )" in p
+    assert "log_prob = log_prob.sum(dim=1, keepdim=True)" in p
+    assert "action = torch.tanh(mean)" in p                      # the deterministic branch MakeDeterministic takes
+    assert "h = self.hidden_activation(fc(h))" in p and "mean = self.last_fc(h)" in p
+    assert "log_std = self.last_fc_log_std(h)" in p
+    m = norm(mlp_src)
+    assert "flat_inputs = torch.cat(inputs, dim=1)" in m and "return super().forward(flat_inputs, **kwargs)" in m
