@@ -219,6 +219,14 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *buf, int64_t token, float di
  * diagnostics of the first and last step (the reference logs the first step of each epoch). */
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *diag_first, float *diag_last);
 
+/* 1 while the trainer runs the FUSED step: launches A + B + C of the step as one launch (k_abc) whose workgroups hand
+ * their partial sums to each other inside the launch, then the weight-gradient / Adam launch -- two launches per step
+ * instead of four.  It needs the chip to itself (every workgroup resident).  A hand-off that times out (50 ms) makes
+ * the step apply NOTHING, the call that notices returns an error, and the trainer falls back to the four-launch step
+ * for good; SAC_FUSED=0 in the environment selects the four-launch step from the start.  Both give identical results
+ * (tests/test_gpu_fused_step.py). */
+int sac_trainer_is_fused(const sac_trainer_t *t);
+
 /* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop, and
  * per-kernel-family device time accumulated over it (names via sac_kernel_name). */
 int sac_sync(sac_trainer_t *t);
@@ -226,7 +234,7 @@ int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float 
 
 /* profiling pass: the same loop with HIP events (on the launching streams) around every kernel.
  * out_ms[9] = {index kernel, gather kernel, then the MEAN per-launch ms of k_fwd_a, k_fwd_b, k_bwd,
- * a reserved slot (0), k_dw_adam (each minus the cost of an empty event pair), that empty-pair cost,
+ * a reserved slot (0), k_dw_adam (fused step: k_abc in the k_fwd_a slot, 0 in the next two) (each minus the cost of an empty event pair), that empty-pair cost,
  * and the wall ms of all n_steps steps}.  n_steps <= 4096. */
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float out_ms[9]);
 

@@ -7,10 +7,15 @@ namespace sac {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// float4 grid-stride copy (16 B per lane, 1 KB per wave-instruction, read + write counted)
+// float4 copy, 16 B per lane, 1 KB per wave-instruction, four independent loads in flight per lane (read + write counted)
 __global__ __launch_bounds__(256) void k_peak_copy(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n4) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = e;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 // back-to-back v_mfma_f32_16x16x4_f32 on 8 independent accumulators per wave, operands in registers (non-trivial

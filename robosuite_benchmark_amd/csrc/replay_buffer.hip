@@ -659,8 +659,8 @@ int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *
                      int64_t *idx_out) {
     SAC_REQUIRE(b && batch > 0, "bad arguments to sac_random_batch");
     SAC_HIP(hipSetDevice(b->device));
+    if (ensure_slots(b, batch, 1)) return -1;          // (first: a layout change clears the index buffer too)
     if (launch_sample(b, batch, 1)) return -1;
-    if (ensure_slots(b, batch, 1)) return -1;
     if (launch_gather(b, b->d_idx, b->slot.B, 1, b->d_slots, b->slot, 1)) return -1;
     if (copy_slot_out(b, 0, obs, act, rew, term, next_obs)) return -1;
     if (idx_out) SAC_HIP(hipMemcpyAsync(idx_out, b->d_idx, sizeof(int64_t) * batch, hipMemcpyDeviceToHost, b->stream));

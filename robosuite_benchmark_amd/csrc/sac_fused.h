@@ -1,0 +1,528 @@
+// k_abc: launches A, B and C of the SAC step as ONE launch (included by sac_trainer.hip, namespace sac).
+//
+// Why: a step is four dependent launches of ~6 us each, and every launch pays (i) ~2.2 us of dispatch boundary,
+// (ii) ~1.3 us until its first data returns and (iii) a cold pass over its weights (the L2s are invalidated at every
+// dispatch; a CU takes in ~50-70 GB/s from the Infinity Cache) before any MFMA runs.  The seams A -> B and B -> C are
+// not all-to-all: launch B needs the four head partials of its own 16-row block, launch C the q / d/da partials of its
+// own row-block plus 16 scalars (the row-block sums of log pi, for the entropy coefficient).  Here the same 16*NB
+// workgroups run all three phases and hand those few KB to each other through HBM inside the launch:
+//
+//   critic chain (twin i, row-block rb, column part p)      policy chain (side s, rb, p)
+//   A  Q_i(s, a): first layer (z kept in registers),         A  pi(side): first layer, 64-column slice, head partial
+//      64-column slice (W2 slice streamed once, staged           --> head[side][rb] published
+//      transposed in LDS), q partial
+//   -- wait head[s][rb] ---------------------------------    -- wait head[s'][rb] ---------------------------------
+//   B  tanh-Gaussian head on s; Q_i(s, a_new): first layer    B  head on s'; T_{side+1}(s', a'): first layer, slice,
+//      = z + W1[:, act] (a_new - a), slice (second, L2-warm      q partial
+//      pass over the same W2 slice), q partial; unit
+//      gradient dQ_i/da from the staged slice (partials)
+//   -- wait phase B of all 16 blocks of rb, and the 16 row-block sums of log pi -------------------------------------
+//   C  critic backward of Q_i (dL/dh kept for dW)             C  side 0: policy backward; side 1: done
+//
+// While a block waits, the weights of its next phase are already in flight (they do not depend on the hand-off), so
+// the cold pass of phases B and C hides behind the wait instead of following a dispatch boundary.
+//
+// Hand-off protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"):
+// producer: payload with agent-scope write-through stores (sc1) -> every storing wave s_waitcnt vmcnt(0) -> workgroup
+// barrier -> ONE lane: agent-scope atomic add on a counter; consumer: one lane polls the counter with sc1 loads (plus
+// s_sleep), workgroup barrier, then loads.  Counters are monotonic (targets are multiples of the launch number:
+// no reset, no ABA).  Every handed-off datum lives in 128-B lines that ONE producer block writes and nobody reads
+// before the counter says so, so neither a CU's L1 nor an XCD's L2 can hold a stale copy of them (both are
+// invalidated at dispatch); 4-byte consumer loads are sc1 (L1-bypassing) on top of that.
+//
+// Residency: the 16*NB blocks (<= 256, ~106 KB of LDS each: one per CU) must all be resident -- true when the launch
+// has the chip to itself.  Nothing spins forever: a wait gives up after 50 ms (s_memrealtime), raises the sticky abort
+// word, every other wait sees it and leaves, launch D then applies NOTHING (the step's only writer of weights, Adam
+// state, targets and the entropy coefficient), and the host reports the error and falls back to the four-launch step.
+// Requirements checked by the host: SAC, column split 4 (batch <= 256), narrow first layers (obs_dim <= 112),
+// at least 16*NB CUs.  Fused launches of different trainers in one process are serialised by the host.
+#pragma once
+
+constexpr int CNT_STRIDE = 32;                                  // unsigned per counter: one 128-B line each
+constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 5000000ull;   // s_memrealtime ticks (100 MHz): 50 ms
+constexpr int FUSED_RED = 2048;                                 // floats of split-K scratch
+
+// one lane: wait until *cnt has reached target (wrap-safe); false = abort (ours or somebody else's)
+__device__ __forceinline__ int handoff_wait(const unsigned *cnt, unsigned target, unsigned *abort_flag) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - target) >= 0) return 1;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 0;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > HANDOFF_TIMEOUT_TICKS) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// every wave: its stores have left; then ONE lane signals for the whole workgroup
+__device__ __forceinline__ void handoff_publish(unsigned *cnt) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// alpha_step with the row-block sums read by vector sc1 loads (they were written earlier in THIS launch); the sum runs
+// in the same order as alpha_step's, so launch D's diagnostics block computes bit-identical state from the same words
+__device__ __forceinline__ AlphaStep alpha_step_v(const Ctl *ctl, const float *part_logpi, int NB, int B, float target_entropy,
+                                                  float lr, int auto_alpha, double bc1, double bc2s) {
+    AlphaStep r;
+    const float la = sload(&ctl->log_alpha), m0 = sload(&ctl->a_m), v0 = sload(&ctl->a_v);
+    if (!auto_alpha) { r.alpha = 1.0f; r.alpha_loss = 0.0f; r.log_alpha = la; r.m = m0; r.v = v0; return r; }
+    const int lane = threadIdx.x & 63;
+    const float mine = ld_sc1(part_logpi + (lane < NB ? lane : 0));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (i < NB) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), i));
+    const float mean_lp = sum / (float)B + target_entropy;
+    r.alpha_loss = -((la * mean_lp) + 0.0f);
+    const float gr = -mean_lp;
+    r.m = m0 + ADAM_1MB1 * (gr - m0);
+    r.v = v0 * ADAM_B2 + ADAM_1MB2 * gr * gr;
+    const float step_size = (float)((double)lr / bc1);
+    const float denom = sqrtf(r.v) / (float)bc2s + 1e-8f;
+    r.log_alpha = la + (-step_size * r.m) / denom;
+    r.alpha = expf(r.log_alpha);
+    return r;
+}
+
+template <int NTH>
+__global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
+    constexpr int SP = 4, SW = 64;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int s_ok;
+    __shared__ float s_dq[RB];
+    const int B = d.B, O = d.O, A = d.A, NB = d.NB;
+    const int KLQ = (d.KQ + 63) & ~63;
+    float *X0 = lds;                     // [16][KLQ]  input rows (phase A), cat(obs, action) (phase B)
+    float *X1 = X0 + RB * KLQ;           // [16][256]
+    float *XS = X1 + RB * H;             // [16][64]
+    float *red = XS + RB * SW;           // FUSED_RED floats of split-K scratch
+    float *WL = red + FUSED_RED;         // [256][WLD]  critic chain: W2 slice, transposed (phase A -> phase B's tail)
+    // XCD-aware map (speed only): b % 8 in {0,1} -> critic chain of Q1, {2,3} -> Q2, {4,5} -> policy chain on s (then T1,
+    // then the policy backward), {6,7} -> policy chain on s' (then T2); the 16 blocks of row-block rb are 16 rb .. 16 rb + 15
+    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
+    const bool isq = xr < 4;
+    const int net = (xr >> 1) & 1;                            // critic chain: twin; policy chain: side
+    const int bi = 2 * xq + (xr & 1);
+    const int part = bi & 3, rb = bi >> 2;
+    const int row0 = rb * RB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int row = threadIdx.x >> 4, a = threadIdx.x & 15, grow = row0 + row;
+    const int n0 = SW * part + 16 * wave;                     // this wave's tile of the split layers
+    unsigned *cnt_head = d.cnt, *cnt_b = d.cnt + (size_t)2 * NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)3 * NB * CNT_STRIDE;
+    const unsigned seq = sa.seq;
+    const bool own_s = isq && net == 0 && part == 0, own_n = !isq && net == 0 && part == 0;
+    // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
+    // one producer block leaves without publishing, so its consumers run into the hand-off timeout
+    if ((sa.pad2 & 1u) && blockIdx.x == 4) return;
+
+    // =========================================================================================================
+    // phase A
+    // =========================================================================================================
+    f32x4 keep1[4], zkeep[4];
+    float bv1[1], w3[4];
+    {
+        const float *P = isq ? d.P[1 + net] : d.P[0];
+        const Layer L0 = isq ? d.LQ[0] : d.LP[0], L1 = isq ? d.LQ[1] : d.LP[1], L2 = isq ? d.LQ[2] : d.LP[2];
+        const int K0 = isq ? d.KQ : d.KP;
+        const float *obs = S + ((!isq && net) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
+        RowRegs<8> rows;
+        rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, isq ? A : 0, A, d.KP);
+        WRing<4, RD0> r0;
+        r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
+        constexpr int PRE0 = 2;
+        r0.fill_part(K0 >> 4, 0, PRE0);
+        float bv0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
+        SB();
+        WRing<1, 8> r1;
+        r1.init(P + L1.offW, H, n0, 16);
+        rows.commit(X0, KLQ, K0, O, d.KP, isq ? A : 0);
+        lds_barrier();
+        {   // first layer, all 256 features (recomputed by the 4 blocks of this row-block)
+            f32x4 acc[4] = {};
+            gemm_straight_pf(r0, X0, KLQ, K0 >> 4, acc, r1, H >> 4, PRE0);
+            // the critic chain keeps the PRE-activation z = W1 [s, a] + b in registers: the layer is linear in the action,
+            // so phase B gets Q_i(s, a_new)'s first layer as z + W1[:, action chunk] (a_new - a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zkeep[t][i] = acc[t][i] + bv0[t];
+            hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, keep1);
+        }
+        lds_barrier();
+        bv1[0] = P[L1.offB + n0 + c];
+        WRing<NTH, 1> rh;                                     // policy chain: head rows x this wave's 16 columns
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w3[u] = 0.f;
+        if (!isq) {
+            rh.init(P + L2.offW, H, 0, 16, 4 * part + wave);
+            rh.fill(1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) w3[u] = P[L2.offW + frag_off(0, SW * part + a + 16 * u, H)];
+        }
+        SB();
+        {   // this block's 64 columns of the 256x256 layer; the critic chain also leaves the slice in LDS, transposed
+            f32x4 acc[1] = {};
+            if (isq) gemm_ring<true>(r1, X1, H, H >> 4, acc, 0, WL + 16 * wave);
+            else gemm_ring(r1, X1, H, H >> 4, acc);
+            // feature-major copies: operands of the weight-gradient launch, and (sc1) of the backward phase of the
+            // sibling blocks of this row-block
+            if (wave == part) {
+                float *h1T = isq ? d.QH1T + (size_t)net * H * B : (net == 0 ? d.PH1T : nullptr);
+                if (h1T) store_features<4, true>(keep1, 64 * wave, 16, h1T, B, row0);
+            }
+            float *h2T = isq ? d.QH2T + (size_t)net * H * B : (net == 0 ? d.PH2T : nullptr);
+            slice_epilogue<1, true>(acc, bv1, wave, XS, h2T, n0, B, row0);
+        }
+        lds_barrier();
+        if (!isq) {     // partial head pre-activations over these 64 columns
+            f32x4 acc[NTH] = {};
+            gemm_ring(rh, XS, SW, 1, acc, wave);
+            splitk_reduce<NTH, true>(acc, nullptr, red, d.headpart + ((size_t)(net * NB + rb) * SP + part) * (RB * 32), 32);
+        } else {        // partial Q_i(s, a) over these 64 columns
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, SW)] * w3[u];
+            s = group16_sum(s);
+            if (a == 0) st_sc1(d.qpart2 + ((size_t)(net * NB + rb) * SP + part) * 32 + row, s);
+        }
+    }
+    if (!isq) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
+
+    // =========================================================================================================
+    // phase B: requests that do not depend on the hand-off first, then the wait
+    // =========================================================================================================
+    const int p4 = isq ? net : 2 + net;                       // Q1, Q2 on (s, a_new) | T1, T2 on (s', a')
+    const int side = isq ? 0 : 1, pass = 2 + p4;
+    const float *PQ = d.P[1 + p4];
+    const int KS0 = d.KQ >> 4, lo0 = isq ? KS0 - 1 : 0;       // critic chain: only the action chunk of the first layer
+    RowRegs<8> rows2;
+    f32x4 acc0[4];
+    float bv0b[4], abat = 0.f;
+    if (isq) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc0[t] = zkeep[t]; bv0b[t] = 0.f; }
+        abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rows2.issue(d.KQ, S + SL.off_nobs + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv0b[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+    }
+    WRing<4, RD0> q0;
+    q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
+    q0.fill_part(KS0, 0, RD0, lo0);
+    WRing<1, 8> q1;
+    q1.init(PQ + d.LQ[1].offW, H, n0, 16);
+    q1.fill(H >> 4);
+    bv1[0] = PQ[d.LQ[1].offB + n0 + c];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[u] = PQ[d.LQ[2].offW + frag_off(0, SW * part + a + 16 * u, H)];
+    const float *epp = side ? d.eps2 : d.eps1;
+    const int am = (a < A) ? a : 0;
+    const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
+    const float epsin = epp ? epp[grow * A + am] : 0.f;
+    SB();
+    if (threadIdx.x == 0) s_ok = handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
+    lds_barrier();
+    if (!s_ok) return;
+    float hm[SP], hr[SP];
+    {
+        const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
+#pragma unroll
+        for (int p = 0; p < SP; ++p) { hm[p] = ld_sc1(hp + p * (RB * 32) + am); hr[p] = ld_sc1(hp + p * (RB * 32) + A + am); }
+    }
+    if (!isq) rows2.commit(X0, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + 16);     // (the head writes the action chunk)
+    // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
+    float lp = 0.f, mean = 0.f, raw = 0.f, lstd = 0.f, stdv = 1.f, eps = 0.f, zz = 0.f, act = 0.f;
+    if (a < A) {
+        mean = hm[0]; raw = hr[0];
+#pragma unroll
+        for (int p = 1; p < SP; ++p) { mean += hm[p]; raw += hr[p]; }     // fixed order
+        mean += hbm; raw += hbr;
+        lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+        stdv = expf(lstd);
+        eps = epp ? epsin : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+        zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                  // TanhNormal.rsample
+        act = tanhf(zz);
+        const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
+        const float var = __fmul_rn(stdv, stdv);
+        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+        lp = nlp - logf(1.0f - act * act + TANH_EPS);
+    }
+    // the whole action chunk (0 beyond A); the critic chain contracts the difference to the batch action
+    X0[lds_off(row, d.KP + a, KLQ)] = (a < A) ? (isq ? act - abat : act) : 0.f;
+    const float lsum = group16_sum(lp);
+    if (own_s && a == 0) red[row] = (grow < d.Bt) ? lsum : 0.f;          // (pad rows carry no weight)
+    lds_barrier();
+    float lsum_blk = 0.f;
+    if (own_s && threadIdx.x == 0) {          // this row-block's sum(log_pi), fixed order
+        for (int i = 0; i < RB; ++i) lsum_blk += red[i];
+    }
+    // ---- Q / target-Q net on cat(obs, action) ----
+    gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
+    hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
+    WRing<1, 4> ra;                                          // W1^T action rows: this wave's 64 first-hidden features
+    if (isq) {
+        SB();
+        ra.init(d.PT[1 + net] + d.LQ[0].offWt, H, d.KP, 16, 4 * wave);      // rows KP.. of W1^T = the action columns
+        ra.fill(4);
+        SB();
+    }
+    lds_barrier();
+    {
+        f32x4 acc[1] = {};
+        gemm_ring(q1, X1, H, H >> 4, acc);
+        // (every load of the forward part has been requested: now the head's global results)
+        if (own_s) {
+            if (a < A) {
+                d.mu[grow * 16 + a] = mean;
+                st_sc1(d.ls + grow * 16 + a, lstd);
+                st_sc1(d.lsok + grow * 16 + a, (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f);
+                d.z[grow * 16 + a] = zz;
+                st_sc1(d.epsv + grow * 16 + a, eps);
+            }
+            st_sc1(d.anew + grow * 16 + a, act);             // (0 beyond A)
+            if (a == 0) d.logpi[grow] = lsum;
+            if (threadIdx.x == 0) st_sc1(d.part_logpi + rb, lsum_blk);
+        } else if (own_n) {
+            d.a2[grow * 16 + a] = act;
+            if (a == 0) { d.logpi2[grow] = lsum; st_sc1(d.logpi2p + rb * 32 + row, lsum); }
+        }
+        slice_epilogue<1>(acc, bv1, wave, XS, nullptr, n0, B, row0);
+    }
+    lds_barrier();
+    {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, SW)] * w3[u];
+        s = group16_sum(s);
+        if (a == 0) st_sc1(d.qpart2 + ((size_t)(pass * NB + rb) * SP + part) * 32 + row, s);
+    }
+    if (own_s && threadIdx.x == 0) {        // the row-block sum of log pi is out: the entropy coefficient of phase C needs all NB of them
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(cnt_lp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (isq) {
+        // ---- actor path: UNIT input gradient of Q_i(s, a_new) (dq = 1), partial over this block's columns ----
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                        // dq/dh2 = w3 * relu'(h2), in place (own elements)
+            const int off = lds_off(row, a + 16 * u, SW);
+            XS[off] = (XS[off] > 0.f) ? w3[u] : 0.f;
+        }
+        lds_barrier();
+        {   // partial dq/dh1 over ALL first-hidden features = dq/dh2[:, slice] . W2[slice, :] (staged in phase A), masked
+            f32x4 acc[4] = {};
+            gemm_lds_rows<4, 4>(WL, 64 * wave, XS, SW, acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = lds_off(4 * g + i, 64 * wave + 16 * t + c, H);
+                    X1[off] = (X1[off] > 0.f) ? acc[t][i] : 0.f;
+                }
+            }
+        }
+        lds_barrier();
+        {   // partial dq/da = dq/dh1 . W1[:, O:O+A]  (contraction split over the waves)
+            f32x4 acc[1] = {};
+            gemm_ring(ra, X1, H, 4, acc, 4 * wave);
+            splitk_reduce<1, true>(acc, nullptr, red, d.dapart + (((size_t)net * SP + part) * B + row0) * 16, 16);
+        }
+    }
+    handoff_publish(cnt_b + (size_t)rb * CNT_STRIDE);
+    if (!isq && net == 1) return;                             // the s' policy chain has no backward of its own
+
+    // =========================================================================================================
+    // phase C: critic backward (critic chain) | policy backward (policy chain on s).  Transposed weights first.
+    // =========================================================================================================
+    const float invB = 1.0f / (float)d.Bt;                   // means run over the true batch; pad rows get no gradient
+    const long long oB3 = d.LQ[2].offB;
+    if (isq) {
+        float *X2 = lds;                                     // dL/dh2 row-block [16][256]
+        const float *P = d.P[1 + net], *PT = d.PT[1 + net];
+        const float *h2T = d.QH2T + (size_t)net * H * B, *h1T = d.QH1T + (size_t)net * H * B;
+        const int k = threadIdx.x;
+        WRing<1, 8> rc;
+        rc.init(PT + d.LQ[1].offWt, H, n0, 16);
+        rc.fill(H >> 4);
+        const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
+        const float b3a = sload(d.P[3] + oB3), b3b = sload(d.P[4] + oB3), b3q = sload(P + oB3);
+        SB();
+        if (threadIdx.x == 0) {
+            int ok = handoff_wait(cnt_b + (size_t)rb * CNT_STRIDE, 16u * seq, d.abort_flag);
+            if (ok) ok = handoff_wait(cnt_lp, (unsigned)NB * seq, d.abort_flag);
+            s_ok = ok;
+        }
+        lds_barrier();
+        if (!s_ok) return;
+        float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;
+#pragma unroll
+        for (int p = 0; p < SP; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
+        if (threadIdx.x < RB) {
+            const int r = row0 + threadIdx.x;
+#pragma unroll
+            for (int p = 0; p < SP; ++p) {
+                qa[p] = ld_sc1(d.qpart2 + ((size_t)(4 * NB + rb) * SP + p) * 32 + threadIdx.x);
+                qb[p] = ld_sc1(d.qpart2 + ((size_t)(5 * NB + rb) * SP + p) * 32 + threadIdx.x);
+                qq[p] = ld_sc1(d.qpart2 + ((size_t)(net * NB + rb) * SP + p) * 32 + threadIdx.x);
+            }
+            in_c = ld_sc1(d.logpi2p + rb * 32 + threadIdx.x);
+            in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
+        }
+        f32x4 h2v[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + frag_off(k, row0 + 4 * qd, B));
+        f32x4 h1v[1];
+        h1v[0] = ld4(h1T + frag_off(n0 + c, row0 + 4 * g, B));
+        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
+        if (threadIdx.x < RB) {
+            va = qa[0]; vb = qb[0]; vq = qq[0];
+#pragma unroll
+            for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; vq += qq[p]; }      // fixed order
+            va += b3a;                                                       // T1(s',a')
+            vb += b3b;                                                       // T2(s',a')
+            vq += b3q;                                                       // Q_i(s,a)
+            const float tq = fminf(va, vb) - alpha * in_c;
+            yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
+            dq = (row0 + (int)threadIdx.x < d.Bt) ? 2.0f * (vq - yv) * invB : 0.f;
+            s_dq[threadIdx.x] = dq;
+        }
+        lds_barrier();
+        // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner block
+        f32x4 gv2[4];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                gv2[qd][i] = (h2v[qd][i] > 0.f) ? s_dq[4 * qd + i] * wk : 0.f;
+                X2[lds_off(4 * qd + i, k, H)] = gv2[qd][i];
+            }
+        }
+        lds_barrier();
+        {   // dL/dh1[:, this block's features] = (dL/dh2 . W2)[:, slice] * relu'(h1)
+            f32x4 acc[1] = {};
+            gemm_ring(rc, X2, H, H >> 4, acc);
+            if (threadIdx.x < RB && part == 0) {
+                const int r = row0 + threadIdx.x;
+                d.q[(size_t)net * B + r] = vq;
+                d.dq16T[(size_t)net * 16 * B + frag_off(0, r, B)] = dq;      // row 0 of the padded [16][B]
+                if (net == 0) { d.y[r] = yv; d.q[4 * (size_t)B + r] = va; d.q[5 * (size_t)B + r] = vb; }
+            }
+            if ((k / SW) == part) {
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) st4(d.dQH2T + (size_t)net * H * B + frag_off(k, row0 + 4 * qd, B), gv2[qd]);
+            }
+            f32x4 gv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? acc[0][i] : 0.f;
+            st4(d.dQH1T + (size_t)net * H * B + frag_off(n0 + c, row0 + 4 * g, B), gv);
+        }
+    } else {
+        // policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient: see policy_bwd_block
+        float *XH = lds;                 // [16][64] head gradient row-block
+        float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the 4 blocks)
+        const float *PT = d.PT[0];
+        const int gi = grow * 16 + a;
+        WRing<4> rh;
+        rh.init(PT + d.LP[2].offWt, d.LP[2].Np, 64 * wave, 16);
+        rh.fill(NTH);
+        WRing<1, 8> r1;
+        r1.init(PT + d.LP[1].offWt, H, n0, 16);
+        r1.fill(H >> 4);
+        const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
+        SB();
+        for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
+        if (threadIdx.x == 0) {
+            int ok = handoff_wait(cnt_b + (size_t)rb * CNT_STRIDE, 16u * seq, d.abort_flag);
+            if (ok) ok = handoff_wait(cnt_lp, (unsigned)NB * seq, d.abort_flag);
+            s_ok = ok;
+        }
+        lds_barrier();
+        if (!s_ok) return;
+        float actv = 0.f, dap[2 * SP], qa[SP], qb[SP], lsv = 0.f, epv = 0.f, okv = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2 * SP; ++p) dap[p] = 0.f;
+#pragma unroll
+        for (int p = 0; p < SP; ++p) {                           // Q1, Q2(s, a_new) partials of this row
+            qa[p] = ld_sc1(d.qpart2 + ((size_t)(2 * NB + rb) * SP + p) * 32 + row);
+            qb[p] = ld_sc1(d.qpart2 + ((size_t)(3 * NB + rb) * SP + p) * 32 + row);
+        }
+        if (a < A) {
+            actv = ld_sc1(d.anew + gi);
+#pragma unroll
+            for (int p = 0; p < 2 * SP; ++p) dap[p] = ld_sc1(d.dapart + (size_t)p * B * 16 + gi);
+            lsv = ld_sc1(d.ls + gi); epv = ld_sc1(d.epsv + gi); okv = ld_sc1(d.lsok + gi);
+        }
+        f32x4 h2v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
+        f32x4 h1v[1];
+        h1v[0] = ld4(d.PH1T + frag_off(n0 + c, row0 + 4 * g, B));
+        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        float qnew1 = 0.f, qnew2 = 0.f, dz = 0.f, dls = 0.f;
+        {
+            float va = qa[0], vb = qb[0];
+#pragma unroll
+            for (int p = 1; p < SP; ++p) { va += qa[p]; vb += qb[p]; }                   // fixed order
+            va += b3a; vb += b3b;                                                        // Q1, Q2(s, a_new)
+            // torch.min backward: the smaller one takes the gradient, a tie splits it
+            const float sel1 = (va < vb) ? 1.0f : ((va == vb) ? 0.5f : 0.0f);
+            const float dq1 = -invB * sel1, dq2 = -invB * (1.0f - sel1);
+            qnew1 = va; qnew2 = vb;
+            if (a < A && grow < d.Bt) {
+                float da1 = dap[0], da2 = dap[SP];
+#pragma unroll
+                for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
+                const float da = da1 * dq1 + da2 * dq2;
+                const float om = 1.0f - actv * actv;
+                dz = da * om + (alpha * invB) * (2.0f * actv * om / (om + TANH_EPS));
+                const float stdv2 = expf(lsv);
+                dls = (dz * stdv2 * epv - alpha * invB) * okv;
+                XH[lds_off(row, A + a, 64)] = dls;
+                XH[lds_off(row, a, 64)] = dz;
+            }
+        }
+        lds_barrier();
+        f32x4 gk2[4];
+        {
+            f32x4 acc[4] = {};
+            gemm_ring(rh, XH, 64, NTH, acc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 64 * wave + 16 * t + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    gk2[t][i] = (h2v[t][i] > 0.f) ? acc[t][i] : 0.f;
+                    X2[lds_off(4 * g + i, n, H)] = gk2[t][i];
+                }
+            }
+        }
+        lds_barrier();
+        {
+            f32x4 acc[1] = {};
+            gemm_ring(r1, X2, H, H >> 4, acc);
+            if (part == 0) {
+                if (a == 0) { d.q[2 * (size_t)B + grow] = qnew1; d.q[3 * (size_t)B + grow] = qnew2; }
+                if (a < A) {
+                    d.dheadT[frag_off(a, grow, B)] = dz;
+                    d.dheadT[frag_off(A + a, grow, B)] = dls;
+                }
+            }
+            if (wave == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
+            f32x4 gv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? acc[0][i] : 0.f;
+            st4(d.dPH1T + frag_off(n0 + c, row0 + 4 * g, B), gv);
+        }
+    }
+}

@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace sac {
@@ -55,6 +56,7 @@ struct StepArg {
     int loop_pos;                  // index of this step inside the current sac_train_loop
     int pad;
     double bc1, bc2s;              // 1 - beta1^t and sqrt(1 - beta2^t), computed on the host in double like torch
+    unsigned seq, pad2;            // fused step: number of this launch (1, 2, ...), the hand-off counters count in units of it
 };
 
 struct Ctl {                       // device-resident state of the entropy coefficient (Adam on log_alpha)
@@ -99,6 +101,11 @@ struct Dev {
     float *y, *dq16T, *dQH2T, *dQH1T, *dheadT, *dPH2T, *dPH1T;
     // partial sums of the column-split layers (added by the consuming launch, fixed order)
     float *headpart, *qpart, *dapart;
+    // fused step (k_abc): per-producer 128-B lines of q partials [pass][row-block][part][32] and of log pi(a'|s')
+    // [row-block][32], hand-off counters (one per 128-B line: head[side][rb], phase-B-done[rb], log-pi partials) and
+    // the sticky abort word (a wait timed out)
+    float *qpart2, *logpi2p;
+    unsigned *cnt, *abort_flag;
     // diagnostics
     float *diag_first, *diag_last, *diag_trace;
     // caller-supplied noise (NULL => counter-based device stream)
@@ -116,7 +123,12 @@ struct DwLayer {
     float lr;
 };
 constexpr int NDW = 9;
-struct DwTable { const DwLayer *L; int job0[NDW]; int njobs; };   // L: device array, read with scalar loads
+struct DwTable {                   // L: device array, read with scalar loads
+    const DwLayer *L;
+    int job0[NDW];
+    int njobs;
+    const unsigned *abort;         // fused step only: nonzero => the forward/backward launch gave up, apply NOTHING
+};
 
 // ------------------------------------------------------------------------------------------
 // in-kernel stamps (diagnostic build only, -DSAC_STAMPS; the shipped library has none)
@@ -384,7 +396,13 @@ constexpr int RD0 = 8;            // narrow first layers: up to 8 k-chunks (K <=
 
 // split-K epilogue: the four waves each hold a partial [16 x 16*NTT]; sum them through LDS into
 // `out` (row-major [16][ldo]) + bias.  red = 4*NTT*256 floats.
-template <int NTT>
+// Stores / loads of data that another workgroup of the SAME launch consumes (fused step, sac_fused.h): agent-scope
+// write-through stores (global_store ... sc1) and L1-bypassing 4-byte loads.
+__device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4_sc1(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+template <int NTT, bool SC1 = false>
 __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const float *__restrict__ bias, float *red,
                                               float *out, int ldo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -397,7 +415,8 @@ __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const flo
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * NTT + t) * 64 + l) * 4 + i];
         const int row = 4 * (l >> 4) + i, col = 16 * t + (l & 15);
-        out[row * ldo + col] = s + (bias ? bias[col] : 0.f);
+        if constexpr (SC1) st_sc1(out + row * ldo + col, s + (bias ? bias[col] : 0.f));
+        else out[row * ldo + col] = s + (bias ? bias[col] : 0.f);
     }
     lds_barrier();
 }
@@ -487,11 +506,15 @@ __device__ __forceinline__ void hidden_epilogue(const f32x4 (&acc)[NT], int n_ba
         }
     }
 }
-template <int NT>
+template <int NT, bool SC1 = false>
 __device__ __forceinline__ void store_features(const f32x4 (&v)[NT], int n_base, int n_stride, float *outT, int B, int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) st4(outT + frag_off(n_base + t * n_stride + c, row0 + 4 * g, B), v[t]);
+    for (int t = 0; t < NT; ++t) {
+        float *p = outT + frag_off(n_base + t * n_stride + c, row0 + 4 * g, B);
+        if constexpr (SC1) st4_sc1(p, v[t]);
+        else st4(p, v[t]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -518,7 +541,7 @@ constexpr int ring_depth(int ntw) { return ntw == 1 ? 8 : 4; }   // k-chunks in 
 
 // relu(acc + bias) of this wave's NTW tiles -> local slice buffer XS[16][64*NTW] and (optionally) the
 // feature-major global rows of those features
-template <int NTW>
+template <int NTW, bool SC1 = false>
 __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const float (&bv)[NTW], int wave, float *XS,
                                                float *outT, int n_first, int B, int row0) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -530,7 +553,11 @@ __device__ __forceinline__ void slice_epilogue(const f32x4 (&acc)[NTW], const fl
             v[i] = fmaxf(acc[t][i] + bv[t], 0.f);
             XS[lds_off(4 * g + i, 16 * (NTW * wave + t) + c, 64 * NTW)] = v[i];
         }
-        if (outT) st4(outT + frag_off(n_first + 16 * t + c, row0 + 4 * g, B), v);
+        if (outT) {
+            float *p = outT + frag_off(n_first + 16 * t + c, row0 + 4 * g, B);
+            if constexpr (SC1) st4_sc1(p, v);
+            else st4(p, v);
+        }
     }
 }
 
@@ -1170,6 +1197,8 @@ __global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S,
     }
 }
 
+#include "sac_fused.h"
+
 // ------------------------------------------------------------------------------------------
 // K5: weight gradients + Adam + Polyak, tile-owner parallel.  One WG owns a 16 (out) x 64 (in)
 // tile of one layer: dW = sum_b dY[b][n] X[b][k] with the batch split over the 4 waves (MFMA
@@ -1273,6 +1302,9 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const Ctl *cp = d.ctl;
+    // fused step: the forward/backward launch gave up (a hand-off wait timed out) => this launch, the step's only
+    // writer of weights, Adam state, targets and the entropy coefficient, applies NOTHING
+    const unsigned aborted = T.abort ? sload(T.abort) : 0u;
 
     if ((int)blockIdx.x < T.njobs) {
         STAMP(4, 0);
@@ -1381,6 +1413,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         lds_barrier();
         STAMP(4, 1);
         const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
+        if (aborted) return;
         if (own_valid) {
             f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1411,6 +1444,9 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
         STAMP(4, 2);
+    } else if (aborted) {
+        // tell the host which launch was the first one not applied (diagnostic slots 30 / 31 are unused)
+        if (threadIdx.x == 0 && d.diag_last[31] == 0.f) { d.diag_last[30] = __builtin_bit_cast(float, sa.seq); d.diag_last[31] = 1.f; }
     } else if (d.algo == 1) {
         td3_diagnostics(d, sa, red);
     } else {
@@ -1532,11 +1568,19 @@ struct sac_trainer {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     static constexpr int NLOOP_EV = 8;
     hipEvent_t ev_ready[NLOOP_EV] = {}, ev_done[NLOOP_EV] = {};                      // chunks of sac_train_loop in flight
-    float *h_diag = nullptr;                          // pinned: first[32] | last[32] of a loop
+    float *h_diag = nullptr, *d_diag_host = nullptr;  // mapped pinned: first[32] | last[32] (host view, device view)
     float last_ms[4] = {0, 0, 0, 0};
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
     size_t lds_bw = 0;
+    // fused step (k_abc, sac_fused.h): launches A + B + C as one launch with in-launch hand-offs
+    bool fused = false;
+    unsigned fused_seq = 0;                           // launches so far: the hand-off counters count in units of it
+    unsigned fused_unchecked = 0;                     // fused launches since the host last looked at the abort marker
+    unsigned test_stall_at = 0;                       // SAC_FUSED_TEST_STALL=<n>: the n-th fused launch loses a producer (tests)
+    void (*abc)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    size_t lds_abc = 0;
+    unsigned *d_sync = nullptr; size_t sync_bytes = 0;   // counters (one per 128-B line) + abort word
     void (*fwd_a)(Dev, const float *, SlotLayout, int) = nullptr;
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     void (*bwd)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
@@ -1668,6 +1712,12 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
 
 // the four launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
 // between the launches (profiling pass only)
+// Fused launches of different trainers (streams) of one process must not overlap on a device: two half-resident grids
+// would wait for each other's CUs until the hand-off timeout.  While more than one fused trainer lives on a device,
+// each fused launch waits for the previous one there and records an event behind itself (host section under a lock).
+struct FusedGate { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; int live = 0; };
+FusedGate g_gate[64];
+
 int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr, bool want_stats = false) {
     if (t->algo == 1) return launch_step_td3(t, S, SL, j, want_stats);
     const Dev &d = t->dev;
@@ -1677,13 +1727,30 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
     const int SPv = t->SP;
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
-    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
-    if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
-    if (ev) SAC_HIP(hipEventRecord(ev[2], s));
-    const int compact = (3 * SPv * NB <= 192) ? 1 : 0;     // see k_bwd
-    hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sa, compact);
-    if (ev) { SAC_HIP(hipEventRecord(ev[3], s)); SAC_HIP(hipEventRecord(ev[4], s)); }
+    if (t->fused) {
+        // two launches: A + B + C as k_abc (in-launch hand-offs), then the weight-gradient / Adam launch
+        sa.seq = ++t->fused_seq;
+        sa.pad2 = (t->test_stall_at && sa.seq == t->test_stall_at) ? 1u : 0u;
+        t->fused_unchecked += 1;
+        FusedGate &G = g_gate[t->device & 63];
+        {
+            std::lock_guard<std::mutex> lk(G.mu);
+            const bool gate = G.live > 1;
+            if (gate && G.last && G.last != s) SAC_HIP(hipStreamWaitEvent(s, G.ev, 0));
+            hipLaunchKernelGGL(t->abc, dim3(16 * NB), dim3(256), t->lds_abc, s, d, S, SL, sa);
+            if (gate) { SAC_HIP(hipEventRecord(G.ev, s)); G.last = s; }
+        }
+        if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); SAC_HIP(hipEventRecord(ev[3], s)); }
+    } else {
+        hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
+        if (ev) SAC_HIP(hipEventRecord(ev[1], s));
+        hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
+        if (ev) SAC_HIP(hipEventRecord(ev[2], s));
+        const int compact = (3 * SPv * NB <= 192) ? 1 : 0;     // see k_bwd
+        hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sa, compact);
+        if (ev) SAC_HIP(hipEventRecord(ev[3], s));
+    }
+    if (ev) SAC_HIP(hipEventRecord(ev[4], s));
     hipLaunchKernelGGL(k_dw_adam, dim3(t->dw.njobs + 1), dim3(256), 0, s, d, t->dw, S, sa);
     if (ev) { SAC_HIP(hipEventRecord(ev[5], s)); SAC_HIP(hipEventRecord(ev[6], s)); }
     SAC_HIP(hipGetLastError());
@@ -1692,6 +1759,34 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     return 0;
 }
 
+// After the stream has drained: did a fused launch give up?  (Launch D of the first such step left the launch number in
+// the pinned diagnostics, applied nothing, and so did every step behind it.)  Roll the host counters back to the
+// applied steps, fall back to the four-launch step for good, and report.
+int check_fused_abort(sac_trainer *t) {
+    const unsigned launched = t->fused_unchecked;
+    t->fused_unchecked = 0;
+    if (!t->fused || t->h_diag[SAC_DIAG_N + 31] == 0.f) return 0;
+    unsigned first_bad = 0;
+    memcpy(&first_bad, &t->h_diag[SAC_DIAG_N + 30], sizeof(unsigned));
+    unsigned lost = t->fused_seq - first_bad + 1;
+    if (lost > launched) lost = launched;
+    t->n_train_steps_total -= lost;
+    t->adam_t -= lost;
+    t->fused = false;
+    t->dw.abort = nullptr;
+    t->h_diag[SAC_DIAG_N + 30] = t->h_diag[SAC_DIAG_N + 31] = 0.f;
+    SAC_HIP(hipMemsetAsync(t->d_sync, 0, t->sync_bytes, t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    {
+        FusedGate &G = g_gate[t->device & 63];
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.live -= 1;
+    }
+    sac::set_error("fused SAC step gave up: a hand-off between its workgroups timed out (is another process or kernel using "
+                   "this GPU?).  The last %u step(s) of the call were NOT applied; this trainer now uses the four-launch "
+                   "step (SAC_FUSED=0 selects it from the start)", lost);
+    return -3;
+}
 
 // sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
 int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
@@ -1769,7 +1864,12 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    SAC_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_diag), sizeof(float) * 2 * SAC_DIAG_N, hipHostMallocDefault));
+    // first[32] | last[32] of the diagnostics live in MAPPED PINNED HOST memory: the one diagnostics workgroup of a step
+    // writes its ~30 floats straight over the link, and a caller reads them after the stream has drained without a
+    // device-to-host copy in its call (that copy was ~10 us of every sac_train_loop / sac_step)
+    SAC_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_diag), sizeof(float) * 2 * SAC_DIAG_N, hipHostMallocMapped));
+    memset(t->h_diag, 0, sizeof(float) * 2 * SAC_DIAG_N);
+    SAC_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&t->d_diag_host), t->h_diag, 0));
     hipStream_t s = t->stream;
     const int B = t->B;
 
@@ -1796,6 +1896,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B}, {&d.QU, 2LL * H * B},
         {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
         {&d.headpart, 2LL * t->NB * 4 * RB * 32}, {&d.qpart, 6LL * 4 * B}, {&d.dapart, 2LL * 4 * B * 16},
+        {&d.qpart2, 6LL * t->NB * 4 * 32}, {&d.logpi2p, 32LL * t->NB},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
     long long tot = 0;
     for (auto &p : parts) tot += round_up64(p.second, 64);
@@ -1806,6 +1907,8 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
     arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
+    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (3 * t->NB + 2);     // head[2][NB], phase-B[NB], log-pi, abort
+    arena.reserve(reinterpret_cast<void **>(&t->d_sync), t->sync_bytes);
     arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW * 3);
     g_arena = nullptr;
     if (arena_commit(arena, &t->arena, s)) return -1;
@@ -1824,8 +1927,10 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     d.td3_clip = td3 ? td3->target_policy_noise_clip : 0.f;
     for (int i = 0; i < 3; ++i) d.PT[i] = t->net[i].PT;
     for (int l = 0; l < 3; ++l) { d.LP[l] = t->net[0].L[l]; d.LQ[l] = t->net[1].L[l]; }
-    d.diag_first = t->d_diag; d.diag_last = t->d_diag + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
+    d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
     d.eps1 = d.eps2 = nullptr;
+    d.cnt = t->d_sync;
+    d.abort_flag = t->d_sync + (size_t)CNT_STRIDE * (3 * t->NB + 1);
 
     // weight-gradient work tables: the 256x256 layers first (longest jobs).  SAC: one table (3 nets).  TD3: the two
     // critics without / with the Polyak targets (the soft update follows the critics' step on policy steps only),
@@ -1865,6 +1970,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         for (int n : nets) add_layer(n, 2, dY2[n], X2[n], 0, lrs[n]);
         T.njobs = job;
         T.L = t->d_dwl + base;
+        T.abort = nullptr;
     };
     if (!td3) build_table(t->dw, {0, 1, 2}, true);
     else {
@@ -1872,7 +1978,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         build_table(t->dw_q_tp, {1, 2}, true);
         build_table(t->dw_pi, {0}, true);
         for (int li = 0; li < NDW; ++li) t->dw_none.job0[li] = 1 << 30;
-        t->dw_none.njobs = 0; t->dw_none.L = t->d_dwl;
+        t->dw_none.njobs = 0; t->dw_none.L = t->d_dwl; t->dw_none.abort = nullptr;
         t->dw = t->dw_q;
     }
     SAC_HIP(hipMemcpyAsync(t->d_dwl, hl.data(), sizeof(DwLayer) * hl.size(), hipMemcpyHostToDevice, s));
@@ -1913,6 +2019,27 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     }
 #undef SAC_PICK
 #undef TD3_PICK
+    // The fused step (sac_fused.h) needs: SAC, column split 4 (at most 16 row-blocks), narrow first layers, and every
+    // one of its 16*NB workgroups resident at once (one per CU: ~106 KB of LDS each).  SAC_FUSED=0 selects the
+    // four-launch step (co-tenant processes on one GPU; ablations).
+    {
+        int cus = 0;
+        SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
+        const char *e = getenv("SAC_FUSED");
+        t->fused = !td3 && t->SP == 4 && !wide && t->NB <= 16 && 16 * t->NB <= cus && !(e && atoi(e) == 0);
+        if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
+        t->abc = (nth == 1) ? &k_abc<1> : &k_abc<2>;
+        t->lds_abc = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + FUSED_RED + H * WLD);
+        if (t->fused) {
+            SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->abc), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)t->lds_abc));
+            t->dw.abort = d.abort_flag;
+            FusedGate &G = g_gate[t->device & 63];
+            std::lock_guard<std::mutex> lk(G.mu);
+            if (!G.ev) SAC_HIP(hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
+            G.live += 1;
+        }
+    }
     if (t->lds_fa > 64 * 1024)
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fa));
@@ -1932,6 +2059,12 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     if (!t) return 0;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    if (t->fused) {
+        FusedGate &G = g_gate[t->device & 63];
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.live -= 1;
+        if (G.last == t->stream) G.last = nullptr;
+    }
     (void)hipFree(t->arena);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->h_diag) (void)hipHostFree(t->h_diag);
@@ -2084,8 +2217,9 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
         t->dev.eps1 = t->dev.eps2 = nullptr;
     }
     if (launch_step(t, t->ext_slot, L, 0, nullptr, diag != nullptr)) return -1;
-    if (diag) SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
     SAC_HIP(hipStreamSynchronize(s));
+    if (check_fused_abort(t)) return -3;
+    if (diag) memcpy(diag, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     t->mirror_valid = false;
     return 0;
 }
@@ -2107,21 +2241,24 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     b->ring_in_use[slot] = true;
     t->mirror_valid = false;
     if (diag) {
-        SAC_HIP(hipMemcpyAsync(diag, t->dev.diag_last, sizeof(float) * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
         SAC_HIP(hipStreamSynchronize(s));
+        if (check_fused_abort(t)) return -3;
+        memcpy(diag, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     }
     return 0;
 }
 
 // Slots of a loop live in a ring of LOOP_RING minibatch slots that is allocated ONCE (first use; never resized with
 // n_steps: a 20-step call behind a 2000-step one must not free / allocate / clear inside the call).  The loop is cut
-// into chunks -- 16, 48, 192, then 256 steps each -- laid out back to back in the ring: while the trainer's stream
-// runs the steps of chunk c, the buffer's stream draws the indices of chunk c+1 (one serial wave) and gathers its
-// slots; the short first chunks let step 0 start behind a 16-step draw + gather instead of a 256-step one.  The
+// into chunks -- 4, 12, 48, 192, then 256 steps each -- laid out back to back in the ring: while the trainer's stream
+// runs the steps of chunk c, the buffer's stream draws the indices of chunk c+1 (one serial wave, ~1.1 us per batch) and
+// gathers its slots; the short first chunks let step 0 start behind a 4-step draw + gather instead of a 256-step one.  The
 // index stream is one in-order sequence on the buffer's stream, so it consumes NumPy's generator exactly like
 // n_steps random_batch calls.
 constexpr int64_t LOOP_CH = 256, LOOP_RING = 2 * LOOP_CH;
-static inline int64_t loop_chunk_len(int64_t done) { return done == 0 ? 16 : (done == 16 ? 48 : (done == 64 ? 192 : LOOP_CH)); }
+static inline int64_t loop_chunk_len(int64_t done) {
+    return done == 0 ? 4 : (done == 4 ? 12 : (done == 16 ? 48 : (done == 64 ? 192 : LOOP_CH)));
+}
 
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
@@ -2166,11 +2303,8 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         done += m;
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
-    // first[32] | last[32] are adjacent on the device: one copy into pinned memory (a copy into the caller's pageable
-    // arrays would be staged by the runtime, twice)
-    if (diag_first || diag_last)
-        SAC_HIP(hipMemcpyAsync(t->h_diag, t->dev.diag_first, sizeof(float) * 2 * SAC_DIAG_N, hipMemcpyDeviceToHost, s));
-    SAC_HIP(hipStreamSynchronize(s));
+    SAC_HIP(hipStreamSynchronize(s));             // (the diagnostics are in mapped pinned memory: nothing to copy)
+    if (check_fused_abort(t)) return -3;
     if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
     if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     SAC_HIP(hipEventElapsedTime(&t->last_ms[1], b->ev[0], b->ev[1]));
@@ -2195,6 +2329,7 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     for (int64_t i = 0; i < n_steps; ++i)
         if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * NE])) return -1;
     SAC_HIP(hipStreamSynchronize(s));
+    if (check_fused_abort(t)) return -3;
     // interval k = launch k between two event records; the empty interval e5->e6 measures what an
     // event pair costs by itself and is subtracted from the kernel intervals (slot 5 of out_ms, once
     // k_policy_bwd, is the second empty interval and reads 0)
@@ -2225,8 +2360,11 @@ int sac_sync(sac_trainer_t *t) {
     SAC_REQUIRE(t, "null trainer");
     SAC_HIP(hipSetDevice(t->device));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    return 0;
+    return check_fused_abort(t);
 }
+
+// 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step
+int sac_trainer_is_fused(const sac_trainer_t *t) { return (t && t->fused) ? 1 : 0; }
 
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms) {
     SAC_REQUIRE(t, "null trainer");

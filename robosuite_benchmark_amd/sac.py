@@ -175,7 +175,12 @@ class SACTrainer:
         self._host_policy_stale = True
         names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_bwd", "reserved", "k_dw_adam",
                  "event_pair", "steps_wall"]
+        if self.is_fused():          # the fused step: k_abc = launches A + B + C in one (the next two slots read 0)
+            names[2], names[3], names[4] = "k_fwd_abc", "fused_b", "fused_c"
         return OrderedDict(zip(names, [float(x) for x in ms]))
+
+    def is_fused(self):
+        return bool(self._h is not None and self._lib.sac_trainer_is_fused(self._h))
 
     def loop_timing_ms(self):
         v = [C.c_float() for _ in range(4)]

@@ -1,0 +1,147 @@
+"""GPU: the fused step (k_abc: launches A + B + C as one launch with in-launch hand-offs, csrc/sac_fused.h) against the
+four-launch step of the same library -- identical arithmetic in identical order, so everything must agree bit for
+bit -- and the give-up path of the hand-offs (timeout -> nothing applied -> error -> four-launch fallback)."""
+import os
+
+import numpy as np
+import pytest
+
+from robosuite_benchmark_amd._lib import DIAG_NAMES
+from tests.helpers import make_pair, synth_transitions
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair_of_hip(O, A, B, seed, noise_seed, **env):
+    """(fused, four-launch) trainers with identical parameters."""
+    old = {k: os.environ.get(k) for k in ("SAC_FUSED", "SAC_FUSED_TEST_STALL")}
+    try:
+        os.environ.pop("SAC_FUSED", None)
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        _, fused = make_pair(O, A, B, seed=seed, noise_seed=noise_seed)
+        os.environ.pop("SAC_FUSED_TEST_STALL", None)
+        os.environ["SAC_FUSED"] = "0"
+        _, plain = make_pair(O, A, B, seed=seed, noise_seed=noise_seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return fused, plain
+
+
+def _buffer(n, O, A, seed):
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=seed, term_frac=0.05)
+    buf = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
+    buf.add_block(obs, act, rew, nobs, term)
+    return buf
+
+
+def _same(sa, sb):
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    for k in sa["opt"]:
+        assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
+
+
+# every sweep shape the fused step serves (narrow first layers, batch <= 256), odd batch sizes (padded row-blocks),
+# one and sixteen row-blocks, both head widths (2A <= 16 and > 16)
+@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 256, 40), (42, 7, 128, 30), (46, 7, 256, 12), (55, 7, 256, 12), (73, 12, 256, 12),
+                                         (86, 14, 256, 12), (89, 14, 256, 12), (64, 4, 128, 12), (50, 4, 100, 12),
+                                         (10, 3, 16, 25), (112, 16, 48, 8), (1, 1, 17, 8), (60, 7, 250, 8)])
+def test_fused_step_equals_four_launch_step_bitwise(O, A, B, steps):
+    fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9)
+    assert fused.is_fused() and not plain.is_fused()
+    bufs = [_buffer(5000, O, A, 8), _buffer(5000, O, A, 8)]
+    for b in bufs:
+        b.seed(31)
+    fa, la = fused.train_loop(bufs[0], steps, batch_size=B)
+    fb, lb = plain.train_loop(bufs[1], steps, batch_size=B)
+    assert np.array_equal(fa, fb) and np.array_equal(la, lb)
+    ta = fused.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
+    tb = plain.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
+    assert np.array_equal(ta, tb)
+    _same(fused.state_dict(), plain.state_dict())
+    for name, n in (("a_new", B * A), ("log_pi", B), ("q1", B), ("q2", B), ("q_target", B), ("q1_new", B), ("q2_new", B),
+                    ("log_pi_next", B)):
+        assert np.array_equal(fused.debug_fetch(name, n), plain.debug_fetch(name, n)), name
+    for name in ("g_policy", "g_qf1", "g_qf2"):
+        n = fused.state_dict()["params"][name[2:]].size
+        assert np.array_equal(fused.debug_fetch(name, n), plain.debug_fetch(name, n)), name
+
+
+def test_which_shapes_take_the_fused_step():
+    for (O, A, B), want in (((42, 7, 256), True), ((42, 7, 512), False), ((379, 6, 256), False), ((112, 7, 64), True),
+                            ((113, 7, 64), False), ((42, 7, 1), True)):
+        _, hip = make_pair(O, A, B, seed=1)
+        assert hip.is_fused() is want, (O, A, B)
+
+
+def test_stepwise_and_host_batches_on_the_fused_step():
+    """sac_step (host batch, caller's noise) and sac_step_device (device batch) drive the same two launches."""
+    O, A, B = 42, 7, 256
+    fused, plain = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    obs, act, rew, term, nobs = synth_transitions(B, O, A, seed=5, term_frac=0.1)
+    rs = np.random.RandomState(1)
+    batch = dict(observations=obs, actions=act, rewards=rew, terminals=term.astype(np.float32), next_observations=nobs)
+    for s in range(6):
+        eps = (rs.normal(size=(B, A)).astype(np.float32), rs.normal(size=(B, A)).astype(np.float32)) if s % 2 else None
+        da, db = fused.train(batch, eps=eps), plain.train(batch, eps=eps)
+        assert np.array_equal(da, db), s
+    bufs = [_buffer(3000, O, A, 1), _buffer(3000, O, A, 1)]
+    for b in bufs:
+        b.seed(7)
+    for _ in range(20):
+        fused.train(bufs[0].random_batch(B))
+        plain.train(bufs[1].random_batch(B))
+    fused._lib.sac_sync(fused._h)
+    _same(fused.state_dict(), plain.state_dict())
+
+
+def test_two_fused_trainers_interleaved_from_one_thread():
+    """Fused launches of different trainers are serialised on the device (two half-resident grids would starve each
+    other): interleaving them without any synchronisation in between must neither hang nor change a result."""
+    O, A, B = 42, 7, 256
+    a, ref = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    b, _ = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    bufs = [_buffer(3000, O, A, 1) for _ in range(3)]
+    for x in bufs:
+        x.seed(7)
+    for _ in range(30):
+        a.train(bufs[0].random_batch(B))          # asynchronous: device batches, no host synchronisation
+        b.train(bufs[1].random_batch(B))
+    for _ in range(30):
+        ref.train(bufs[2].random_batch(B))
+    for t in (a, b, ref):
+        t._lib.sac_sync(t._h)
+    _same(a.state_dict(), ref.state_dict())
+    _same(b.state_dict(), ref.state_dict())
+
+
+def test_a_lost_producer_ends_in_an_error_not_a_hang_and_nothing_is_applied():
+    """Launch 3 of the loop loses one producer workgroup (test hook): its consumers give up after the hand-off timeout,
+    launch D of that step and of every later one applies nothing, the call reports the error, the counters say two steps,
+    the state equals two steps of the four-launch path bit for bit, and the trainer carries on with four launches."""
+    O, A, B = 42, 7, 256
+    fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9, SAC_FUSED_TEST_STALL=3)
+    bufs = [_buffer(4000, O, A, 8), _buffer(4000, O, A, 8)]
+    for b in bufs:
+        b.seed(31)
+    assert fused.is_fused()
+    with pytest.raises(RuntimeError, match="gave up"):
+        fused.train_loop(bufs[0], 10, batch_size=B)
+    assert not fused.is_fused()
+    plain.train_loop(bufs[1], 2, batch_size=B)
+    _same(fused.state_dict(), plain.state_dict())
+    assert fused.state_dict()["scalars"][3] == 2 and fused.state_dict()["scalars"][4] == 2
+    # both continue on the four-launch step: same batches from here on (re-seed both streams)
+    for b in bufs:
+        b.seed(32)
+    _, la = fused.train_loop(bufs[0], 15, batch_size=B)
+    _, lb = plain.train_loop(bufs[1], 15, batch_size=B)
+    assert np.array_equal(la, lb) and np.all(np.isfinite(la))
+    _same(fused.state_dict(), plain.state_dict())
