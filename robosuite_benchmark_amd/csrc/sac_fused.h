@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
     // one producer block leaves without publishing, so its consumers run into the hand-off timeout
     if ((sa.pad2 & 1u) && blockIdx.x == 4) return;
+    STAMP(0, 0);
 
     // =========================================================================================================
     // phase A
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             if (a == 0) st_sc1(d.qpart2 + ((size_t)(net * NB + rb) * SP + part) * 32 + row, s);
         }
     }
+    STAMP(0, 1);
     if (!isq) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
+    STAMP(0, 2);
 
     // =========================================================================================================
     // phase B: requests that do not depend on the hand-off first, then the wait
@@ -203,6 +206,26 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const int side = isq ? 0 : 1, pass = 2 + p4;
     const float *PQ = d.P[1 + p4];
     const int KS0 = d.KQ >> 4, lo0 = isq ? KS0 - 1 : 0;       // critic chain: only the action chunk of the first layer
+    // The N(0,1) draw of rsample does not depend on the hand-off: it is computed in front of the wait.  Then the wait
+    // itself, with NOTHING of this block in flight (a poll queued behind a CU's own weight requests returns only when
+    // they have: +1-2 us), and only then the weight requests -- they land under the head math.
+    const float *epp = side ? d.eps2 : d.eps1;
+    const int am = (a < A) ? a : 0;
+    const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
+    float eps = 0.f;
+    if (a < A)
+        eps = epp ? epp[grow * A + am]
+                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+    if (threadIdx.x == 0) s_ok = handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
+    lds_barrier();
+    if (!s_ok) return;
+    STAMP(0, 3);
+    float hm[SP], hr[SP];
+    {
+        const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
+#pragma unroll
+        for (int p = 0; p < SP; ++p) { hm[p] = ld_sc1(hp + p * (RB * 32) + am); hr[p] = ld_sc1(hp + p * (RB * 32) + A + am); }
+    }
     RowRegs<8> rows2;
     f32x4 acc0[4];
     float bv0b[4], abat = 0.f;
@@ -226,23 +249,11 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     bv1[0] = PQ[d.LQ[1].offB + n0 + c];
 #pragma unroll
     for (int u = 0; u < 4; ++u) w3[u] = PQ[d.LQ[2].offW + frag_off(0, SW * part + a + 16 * u, H)];
-    const float *epp = side ? d.eps2 : d.eps1;
-    const int am = (a < A) ? a : 0;
-    const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
-    const float epsin = epp ? epp[grow * A + am] : 0.f;
     SB();
-    if (threadIdx.x == 0) s_ok = handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
-    lds_barrier();
-    if (!s_ok) return;
-    float hm[SP], hr[SP];
-    {
-        const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
-#pragma unroll
-        for (int p = 0; p < SP; ++p) { hm[p] = ld_sc1(hp + p * (RB * 32) + am); hr[p] = ld_sc1(hp + p * (RB * 32) + A + am); }
-    }
     if (!isq) rows2.commit(X0, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + 16);     // (the head writes the action chunk)
     // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same) ----
-    float lp = 0.f, mean = 0.f, raw = 0.f, lstd = 0.f, stdv = 1.f, eps = 0.f, zz = 0.f, act = 0.f;
+    float lp = 0.f, mean = 0.f, raw = 0.f, lstd = 0.f, stdv = 1.f, zz = 0.f, act = 0.f;
+    USE_FROM_HERE(hm[0]);
     if (a < A) {
         mean = hm[0]; raw = hr[0];
 #pragma unroll
@@ -250,7 +261,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         mean += hbm; raw += hbr;
         lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
         stdv = expf(lstd);
-        eps = epp ? epsin : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
         zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                  // TanhNormal.rsample
         act = tanhf(zz);
         const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     if (own_s && threadIdx.x == 0) {          // this row-block's sum(log_pi), fixed order
         for (int i = 0; i < RB; ++i) lsum_blk += red[i];
     }
+    STAMP(0, 4);
     // ---- Q / target-Q net on cat(obs, action) ----
     gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
     hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         s = group16_sum(s);
         if (a == 0) st_sc1(d.qpart2 + ((size_t)(pass * NB + rb) * SP + part) * 32 + row, s);
     }
+    STAMP(0, 5);
     if (own_s && threadIdx.x == 0) {        // the row-block sum of log pi is out: the entropy coefficient of phase C needs all NB of them
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(cnt_lp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -338,7 +350,9 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             splitk_reduce<1, true>(acc, nullptr, red, d.dapart + (((size_t)net * SP + part) * B + row0) * 16, 16);
         }
     }
+    STAMP(0, 6);
     handoff_publish(cnt_b + (size_t)rb * CNT_STRIDE);
+    STAMP(0, 7);
     if (!isq && net == 1) return;                             // the s' policy chain has no backward of its own
 
     // =========================================================================================================
@@ -364,6 +378,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
         lds_barrier();
         if (!s_ok) return;
+        STAMP(0, 8);
         float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;
 #pragma unroll
         for (int p = 0; p < SP; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
@@ -427,6 +442,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? acc[0][i] : 0.f;
             st4(d.dQH1T + (size_t)net * H * B + frag_off(n0 + c, row0 + 4 * g, B), gv);
         }
+        STAMP(0, 9);
     } else {
         // policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient: see policy_bwd_block
         float *XH = lds;                 // [16][64] head gradient row-block
@@ -449,6 +465,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
         lds_barrier();
         if (!s_ok) return;
+        STAMP(0, 8);
         float actv = 0.f, dap[2 * SP], qa[SP], qb[SP], lsv = 0.f, epv = 0.f, okv = 0.f;
 #pragma unroll
         for (int p = 0; p < 2 * SP; ++p) dap[p] = 0.f;
@@ -524,5 +541,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? acc[0][i] : 0.f;
             st4(d.dPH1T + frag_off(n0 + c, row0 + 4 * g, B), gv);
         }
+        STAMP(0, 9);
     }
 }

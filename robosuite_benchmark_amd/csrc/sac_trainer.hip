@@ -273,6 +273,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
     const int r = lane & 15, g = lane >> 4;
     const float *xrow = X + r * KL;
     f32x4 a_cur = ld4(xrow + 4 * ((4 * s_off + g) ^ r));
+    f32x4 acc_odd = {0.f, 0.f, 0.f, 0.f};
     for (int S0 = 0; S0 < KS; S0 += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) {
@@ -293,9 +294,16 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 SB();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if constexpr (NT == 1) {
+                        // one tile per wave = one dependency chain: consecutive MFMAs alternate between two accumulators
+                        // (a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32)
+                        if (i & 1) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][0][i], acc_odd, 0, 0, 0);
+                        else acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][0][i], acc[0], 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][t][i], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][t][i], acc[t], 0, 0, 0);
+                    }
                 }
                 SB();
                 if (S + D < KS) {
@@ -307,6 +315,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
             }
         }
     }
+    if constexpr (NT == 1) acc[0] += acc_odd;
 }
 
 // acc[t] += X[16 x 16*KS] * W[16*KS rows][16 columns at col0 + 16 t] from the slice staged by gemm_ring
@@ -1451,10 +1460,22 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         td3_diagnostics(d, sa, red);
     } else {
         // ---- diagnostics block (SURVEY Appendix A line 17): one pass, wave-shuffle reductions ----
-        const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
-        const float alpha = as.alpha, alpha_loss = as.alpha_loss;
+        STAMP(3, 0);
+        // This ONE block must not outlast the ~245 tile-owner blocks of the launch (it did: 7.6 us against 4.9): every
+        // load of a pass is requested up front -- thread = batch row, its 16-float rows of mu / log_std as four 16-B loads
+        // each, unconditional with a clamped index -- and only then the entropy coefficient (scalar loads + expf) and the
+        // accumulation run, so the block pays one memory round trip instead of one per loop iteration.
         const int loop_pos = sa.loop_pos;
         const int Bt = d.Bt;                 // statistics and losses run over the true batch (B is the padded row stride)
+        const int i_first = (threadIdx.x < Bt) ? (int)threadIdx.x : 0;
+        float yv0 = d.y[i_first], q10 = d.q[i_first], q20 = d.q[(size_t)B + i_first], lp0 = d.logpi[i_first];
+        float qa0 = d.q[2 * (size_t)B + i_first], qb0 = d.q[3 * (size_t)B + i_first];
+        f32x4 mu0[4], ls0[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu0[j] = ld4(d.mu + (size_t)i_first * 16 + 4 * j); ls0[j] = ld4(d.ls + (size_t)i_first * 16 + 4 * j); }
+        SB();
+        const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
+        const float alpha = as.alpha, alpha_loss = as.alpha_loss;
         double sm[NSTAT], sq[NSTAT], ls4[4];
         float mx[NSTAT], mn[NSTAT];
 #pragma unroll
@@ -1462,17 +1483,27 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 #pragma unroll
         for (int q = 0; q < 4; ++q) ls4[q] = 0;
         auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
-        for (int i = threadIdx.x; i < Bt; i += 256) {
-            const float yv = d.y[i], q1 = d.q[i], q2 = d.q[(size_t)B + i], lp = d.logpi[i];
-            const float e1 = q1 - yv, e2 = q2 - yv;
-            const float qn = fminf(d.q[2 * (size_t)B + i], d.q[3 * (size_t)B + i]);
-            ls4[0] += (double)e1 * e1; ls4[1] += (double)e2 * e2;
-            ls4[2] += (double)(lp - qn); ls4[3] += (double)(alpha * lp - qn);
-            acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, lp);
-        }
-        for (int e = threadIdx.x; e < Bt * d.A; e += 256) {
-            const int i = e / d.A, jj = e - i * d.A;
-            acc1(4, d.mu[i * 16 + jj]); acc1(5, d.ls[i * 16 + jj]);
+        for (int i0 = 0; i0 < Bt; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            if (i < Bt) {
+                const float e1 = q10 - yv0, e2 = q20 - yv0;
+                const float qn = fminf(qa0, qb0);
+                ls4[0] += (double)e1 * e1; ls4[1] += (double)e2 * e2;
+                ls4[2] += (double)(lp0 - qn); ls4[3] += (double)(alpha * lp0 - qn);
+                acc1(0, q10); acc1(1, q20); acc1(2, yv0); acc1(3, lp0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (4 * j + u < d.A) { acc1(4, mu0[j][u]); acc1(5, ls0[j][u]); }
+            }
+            if (i0 + 256 < Bt) {             // batches above 256 rows: the next pass's row
+                const int n = (i + 256 < Bt) ? i + 256 : 0;
+                yv0 = d.y[n]; q10 = d.q[n]; q20 = d.q[(size_t)B + n]; lp0 = d.logpi[n];
+                qa0 = d.q[2 * (size_t)B + n]; qb0 = d.q[3 * (size_t)B + n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { mu0[j] = ld4(d.mu + (size_t)n * 16 + 4 * j); ls0[j] = ld4(d.ls + (size_t)n * 16 + 4 * j); }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1533,6 +1564,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (loop_pos == 0) d.diag_first[di] = v;
             if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
         }
+        STAMP(3, 1);
     }
 }
 

@@ -1,0 +1,39 @@
+"""Diagnostic: in-kernel wall-clock stamps of the fused step k_abc (needs the -DSAC_STAMPS build:
+scratch/libsac_hip_stamps_<tag>.so).   usage: python scratch/stamps_fused.py <tag> [batch]"""
+import ctypes as C, sys, os, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from robosuite_benchmark_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsac_hip_stamps_%s.so" % sys.argv[1])
+import bench
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+tr, buf = bench.build_replica("Lift", 42, 7, B, 100_000, 17, 0)
+tr.train_loop(buf, 200, batch_size=B)
+lib = _lib.load()
+out = np.zeros(5 * 512 * 16, np.uint64)
+lib.sac_fetch_stamps.argtypes = [C.c_void_p, C.c_void_p]
+lib.sac_fetch_stamps(tr._h, out.ctypes.data_as(C.c_void_p))
+st = out.reshape(5, 512, 16).astype(np.int64)
+w = st[0]
+blocks = [b for b in range(512) if w[b, 0] > 0]
+t0 = min(w[b, 0] for b in blocks)
+names = ["start", "A done", "A published", "B wait over", "head done", "q partial out", "B done", "B published", "C wait over", "end"]
+for sel, name in ((lambda b: (b & 7) < 4, "critic chain"), (lambda b: (b & 7) in (4, 5), "policy chain s"),
+                  (lambda b: (b & 7) in (6, 7), "policy chain s'")):
+    bl = [b for b in blocks if sel(b)]
+    ww = w[bl]
+    ns = 10 if name != "policy chain s'" else 8
+    med = [np.median(ww[:, i] - t0) / 100.0 for i in range(ns)]
+    mx = [(ww[:, i].max() - t0) / 100.0 for i in range(ns)]
+    print(f"{name} n={len(bl)}")
+    for i in range(ns):
+        print(f"   {names[i]:>14s}: median {med[i]:6.2f}  max {mx[i]:6.2f}")
+w4 = st[4]
+b4 = [b for b in range(512) if w4[b, 0] > 0]
+if b4:
+    t4 = min(w4[b, 0] for b in b4)
+    print("k_dw_adam: start spread", (max(w4[b, 0] for b in b4) - t4) / 100.0, "end max", (w4[b4][:, 2].max() - t4) / 100.0,
+          "| gap abc end -> dw start", (t4 - max(w[b, 9] for b in blocks if (b & 7) < 6)) / 100.0)
+w3 = st[3]
+b3 = [b for b in range(512) if w3[b, 0] > 0]
+if b3 and b4:
+    print("diagnostics block: starts", (w3[b3[0], 0] - t4) / 100.0, "after the first dW block, ends", (w3[b3[0], 1] - t4) / 100.0)
