@@ -57,6 +57,21 @@ __device__ __forceinline__ int handoff_wait(const unsigned *cnt, unsigned target
     }
 }
 
+// Wave 0: lanes 0 .. n-1 wait for one counter each -- ONE memory round trip per poll iteration for all of them
+// (three waits one after the other cost three round trips: +0.8 us measured).  *s_ok = 1 iff every counter got there.
+__device__ __forceinline__ void handoff_wait_multi(int n, const unsigned *c0, unsigned t0, const unsigned *c1, unsigned t1,
+                                                   const unsigned *c2, unsigned t2, unsigned *abort_flag, int *s_ok) {
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        const unsigned *c = (l == 0) ? c0 : ((l == 1) ? c1 : c2);
+        const unsigned t = (l == 0) ? t0 : ((l == 1) ? t1 : t2);
+        int ok = 1;
+        if (l < n) ok = handoff_wait(c, t, abort_flag);
+        const unsigned long long all = __ballot(ok != 0);
+        if (l == 0) *s_ok = (all == ~0ull) ? 1 : 0;
+    }
+}
+
 // every wave: its stores have left; then ONE lane signals for the whole workgroup
 __device__ __forceinline__ void handoff_publish(unsigned *cnt) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -113,7 +128,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15, grow = row0 + row;
     const int n0 = SW * part + 16 * wave;                     // this wave's tile of the split layers
-    unsigned *cnt_head = d.cnt, *cnt_b = d.cnt + (size_t)2 * NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)3 * NB * CNT_STRIDE;
+    // counters (one per 128-B line): head[side][rb] (policy chain, phase A), qa[rb] (critic chain, phase A), tq[rb] (policy
+    // chains, phase B), ac[rb] (critic chain, phase B incl. the actor tail), lp (row-block sums of log pi)
+    unsigned *cnt_head = d.cnt, *cnt_qa = d.cnt + (size_t)2 * NB * CNT_STRIDE, *cnt_tq = d.cnt + (size_t)3 * NB * CNT_STRIDE,
+             *cnt_ac = d.cnt + (size_t)4 * NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)5 * NB * CNT_STRIDE;
     const unsigned seq = sa.seq;
     const bool own_s = isq && net == 0 && part == 0, own_n = !isq && net == 0 && part == 0;
     // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
@@ -196,6 +214,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
     }
     STAMP(0, 1);
+    // (the critic chain's phase-A results -- q partial, h2 slice -- are read by its siblings' backward phase: it signals
+    //  them behind the head wait below, when their stores have long left, instead of draining them here)
     if (!isq) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
     STAMP(0, 2);
 
@@ -216,9 +236,16 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     if (a < A)
         eps = epp ? epp[grow * A + am]
                   : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+    // (a handful of small loads that do not depend on the hand-off either: the s' rows of the target net / the batch action)
+    RowRegs<8> rows2;
+    float abat = 0.f;
+    if (isq) abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
+    else rows2.issue(d.KQ, S + SL.off_nobs + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
     if (threadIdx.x == 0) s_ok = handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
+    if (isq) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // phase A's stores (and two small loads): long done
     lds_barrier();
     if (!s_ok) return;
+    if (isq && threadIdx.x == 0) __hip_atomic_fetch_add(cnt_qa + (size_t)rb * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(0, 3);
     float hm[SP], hr[SP];
     {
@@ -226,17 +253,14 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
 #pragma unroll
         for (int p = 0; p < SP; ++p) { hm[p] = ld_sc1(hp + p * (RB * 32) + am); hr[p] = ld_sc1(hp + p * (RB * 32) + A + am); }
     }
-    RowRegs<8> rows2;
     f32x4 acc0[4];
-    float bv0b[4], abat = 0.f;
+    float bv0b[4];
     if (isq) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc0[t] = zkeep[t]; bv0b[t] = 0.f; }
-        abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        rows2.issue(d.KQ, S + SL.off_nobs + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv0b[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
     }
@@ -351,12 +375,14 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
     }
     STAMP(0, 6);
-    handoff_publish(cnt_b + (size_t)rb * CNT_STRIDE);
+    handoff_publish((isq ? cnt_ac : cnt_tq) + (size_t)rb * CNT_STRIDE);
     STAMP(0, 7);
-    if (!isq && net == 1) return;                             // the s' policy chain has no backward of its own
 
     // =========================================================================================================
-    // phase C: critic backward (critic chain) | policy backward (policy chain on s).  Transposed weights first.
+    // phase C.  Critic chain: critic backward of Q_i as soon as the TARGET partials of the row-block are out (it does
+    // not need the actor tails).  Policy chains (both: s and s' share it, 32 of the 64 dL/dh1 features each): policy
+    // backward once the eight actor tails of the row-block are out.  Everything that does not depend on those hand-offs
+    // -- transposed weights, activation masks, the entropy coefficient -- is requested / computed in front of the wait.
     // =========================================================================================================
     const float invB = 1.0f / (float)d.Bt;                   // means run over the true batch; pad rows get no gradient
     const long long oB3 = d.LQ[2].offB;
@@ -365,20 +391,16 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const float *P = d.P[1 + net], *PT = d.PT[1 + net];
         const float *h2T = d.QH2T + (size_t)net * H * B, *h1T = d.QH1T + (size_t)net * H * B;
         const int k = threadIdx.x;
-        WRing<1, 8> rc;
-        rc.init(PT + d.LQ[1].offWt, H, n0, 16);
-        rc.fill(H >> 4);
-        const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
-        const float b3a = sload(d.P[3] + oB3), b3b = sload(d.P[4] + oB3), b3q = sload(P + oB3);
-        SB();
-        if (threadIdx.x == 0) {
-            int ok = handoff_wait(cnt_b + (size_t)rb * CNT_STRIDE, 16u * seq, d.abort_flag);
-            if (ok) ok = handoff_wait(cnt_lp, (unsigned)NB * seq, d.abort_flag);
-            s_ok = ok;
-        }
+        // the three counters in ONE round trip, with nothing of this block in flight; the target partials have usually been
+        // out for a microsecond by now (the policy chains have no actor tail)
+        handoff_wait_multi(3, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp,
+                           (unsigned)NB * seq, d.abort_flag, &s_ok);
         lds_barrier();
         if (!s_ok) return;
         STAMP(0, 8);
+        WRing<1, 8> rc;
+        const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
+        const float b3a = sload(d.P[3] + oB3), b3b = sload(d.P[4] + oB3), b3q = sload(P + oB3);
         float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;
 #pragma unroll
         for (int p = 0; p < SP; ++p) { qa[p] = 0.f; qb[p] = 0.f; qq[p] = 0.f; }
@@ -398,6 +420,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + frag_off(k, row0 + 4 * qd, B));
         f32x4 h1v[1];
         h1v[0] = ld4(h1T + frag_off(n0 + c, row0 + 4 * g, B));
+        SB();
+        rc.init(PT + d.LQ[1].offWt, H, n0, 16);              // (needed behind dq -> dL/dh2: requested behind the small loads)
+        rc.fill(H >> 4);
+        SB();
         const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
         if (threadIdx.x < RB) {
@@ -444,25 +470,34 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
         STAMP(0, 9);
     } else {
-        // policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient: see policy_bwd_block
+        // policy backward (actor loss = mean(alpha*log_pi - min Q)), analytic head gradient: see policy_bwd_block.
+        // Block (side, rb, part) owns dL/dh1 features 64 part + 32 side .. + 32: waves {0,1} / {2,3} contract the first /
+        // second half of the 256 dL/dh2 features for the two 16-feature tiles, the halves meet in LDS.
         float *XH = lds;                 // [16][64] head gradient row-block
-        float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the 4 blocks)
+        float *X2 = XH + RB * 64;        // [16][256] dL/dh2 (recomputed by the 8 blocks of the row-block)
         const float *PT = d.PT[0];
         const int gi = grow * 16 + a;
+        const int nt = SW * part + 32 * net + 16 * (wave & 1), kh = wave >> 1;   // this wave's tile / half of the contraction
         WRing<4> rh;
         rh.init(PT + d.LP[2].offWt, d.LP[2].Np, 64 * wave, 16);
         rh.fill(NTH);
         WRing<1, 8> r1;
-        r1.init(PT + d.LP[1].offWt, H, n0, 16);
-        r1.fill(H >> 4);
+        r1.init(PT + d.LP[1].offWt, H, nt, 16, 8 * kh);
+        r1.fill(8);
         const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
         SB();
         for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
-        if (threadIdx.x == 0) {
-            int ok = handoff_wait(cnt_b + (size_t)rb * CNT_STRIDE, 16u * seq, d.abort_flag);
-            if (ok) ok = handoff_wait(cnt_lp, (unsigned)NB * seq, d.abort_flag);
-            s_ok = ok;
-        }
+        handoff_wait_multi(2, cnt_head + (size_t)rb * CNT_STRIDE, 4u * seq, cnt_lp, (unsigned)NB * seq, cnt_lp, (unsigned)NB * seq,
+                           d.abort_flag, &s_ok);               // pi(s) blocks' phase A (long done), the log-pi sums
+        lds_barrier();
+        if (!s_ok) return;
+        f32x4 h2v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
+        f32x4 h1v[1];
+        h1v[0] = ld4(d.PH1T + frag_off(nt + c, row0 + 4 * g, B));
+        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        if (threadIdx.x == 0) s_ok = handoff_wait(cnt_ac + (size_t)rb * CNT_STRIDE, 8u * seq, d.abort_flag);   // the eight actor tails
         lds_barrier();
         if (!s_ok) return;
         STAMP(0, 8);
@@ -480,12 +515,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             for (int p = 0; p < 2 * SP; ++p) dap[p] = ld_sc1(d.dapart + (size_t)p * B * 16 + gi);
             lsv = ld_sc1(d.ls + gi); epv = ld_sc1(d.epsv + gi); okv = ld_sc1(d.lsok + gi);
         }
-        f32x4 h2v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
-        f32x4 h1v[1];
-        h1v[0] = ld4(d.PH1T + frag_off(n0 + c, row0 + 4 * g, B));
-        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         float qnew1 = 0.f, qnew2 = 0.f, dz = 0.f, dls = 0.f;
         {
             float va = qa[0], vb = qb[0];
@@ -527,19 +556,26 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         lds_barrier();
         {
             f32x4 acc[1] = {};
-            gemm_ring(r1, X2, H, H >> 4, acc);
-            if (part == 0) {
+            gemm_ring(r1, X2, H, 8, acc, 8 * kh);
+            if (net == 0 && part == 0) {
                 if (a == 0) { d.q[2 * (size_t)B + grow] = qnew1; d.q[3 * (size_t)B + grow] = qnew2; }
                 if (a < A) {
                     d.dheadT[frag_off(a, grow, B)] = dz;
                     d.dheadT[frag_off(A + a, grow, B)] = dls;
                 }
             }
-            if (wave == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
-            f32x4 gv;
+            if (net == 0 && wave == part) store_features<4>(gk2, 64 * wave, 16, d.dPH2T, B, row0);
+            // the two halves of the contraction meet in LDS (fixed order: first half + second half)
+            float *hx = X2 + RB * H;         // 2 tiles x 64 lanes x 4 floats behind the row-block
+            if (kh == 1) st4(hx + ((wave & 1) * 64 + lane) * 4, acc[0]);
+            lds_barrier();
+            if (kh == 0) {
+                const f32x4 o = ld4(hx + ((wave & 1) * 64 + lane) * 4);
+                f32x4 gv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? acc[0][i] : 0.f;
-            st4(d.dPH1T + frag_off(n0 + c, row0 + 4 * g, B), gv);
+                for (int i = 0; i < 4; ++i) gv[i] = (h1v[0][i] > 0.f) ? (acc[0][i] + o[i]) : 0.f;
+                st4(d.dPH1T + frag_off(nt + c, row0 + 4 * g, B), gv);
+            }
         }
         STAMP(0, 9);
     }

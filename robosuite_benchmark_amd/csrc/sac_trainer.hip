@@ -107,7 +107,8 @@ struct Dev {
     float *qpart2, *logpi2p;
     unsigned *cnt, *abort_flag;
     // diagnostics
-    float *diag_first, *diag_last, *diag_trace;
+    float *diag_first, *diag_last, *diag_trace;      // first / last: mapped pinned host memory; trace: device
+    float *diag_dev;                                  // device scratch for the steps whose diagnostics nobody reads
     // caller-supplied noise (NULL => counter-based device stream)
     const float *eps1, *eps2;
 };
@@ -409,7 +410,11 @@ constexpr int RD0 = 8;            // narrow first layers: up to 8 k-chunks (K <=
 // write-through stores (global_store ... sc1) and L1-bypassing 4-byte loads.
 __device__ __forceinline__ void st_sc1(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_sc1(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st4_sc1(float *p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+// (inline asm: the compiler's hazard recogniser does not see a VMEM store in it, and a store of more than 8 bytes
+//  followed by a VALU write of its data registers needs 2 wait states on gfx94x/gfx950 -- hence the s_nop)
+__device__ __forceinline__ void st4_sc1(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
 
 template <int NTT, bool SC1 = false>
 __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const float *__restrict__ bias, float *red,
@@ -1102,9 +1107,18 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
 #pragma unroll
     for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
     SB();
-    WRing<NTW, ring_depth(NTW)> r1;
+    // One tile per wave (SP = 4): the contraction over the 256 dL/dh2 features runs as two halves of eight k-chunks,
+    // each with its own ring (everything requested up front, no refills) and its own accumulators, added at the end --
+    // the order in which the fused step (sac_fused.h), where two waves share a tile, sums them.
+    WRing<NTW, ring_depth(NTW)> r1, r1b;
     r1.init(PT + d.LP[1].offWt, H, n0, 16);
-    r1.fill(H >> 4);
+    if constexpr (NTW == 1) {
+        r1.fill(8);
+        r1b.init(PT + d.LP[1].offWt, H, n0, 16, 8);
+        r1b.fill(8);
+    } else {
+        r1.fill(H >> 4);
+    }
     SB();
     f32x4 h1v[NTW];
 #pragma unroll
@@ -1165,7 +1179,14 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
     lds_barrier();
     {
         f32x4 acc[NTW] = {};
-        gemm_ring(r1, X2, H, H >> 4, acc);
+        if constexpr (NTW == 1) {
+            f32x4 acc_hi[NTW] = {};
+            gemm_ring(r1, X2, H, 8, acc);
+            gemm_ring(r1b, X2, H, 8, acc_hi, 8);
+            acc[0] += acc_hi[0];
+        } else {
+            gemm_ring(r1, X2, H, H >> 4, acc);
+        }
         // global results only now that every load has been requested (vmcnt retires loads and stores in issue order)
         if (part == 0) {
             if (a == 0) { d.q[2 * (size_t)B + row0 + row] = qnew1; d.q[3 * (size_t)B + row0 + row] = qnew2; }
@@ -1274,8 +1295,9 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
         sh[wave * 32 + 24] = lsum;
     }
     lds_barrier();
+    float *const dlast = (sa.pad2 & 2u) ? d.diag_last : d.diag_dev;
     auto put = [&](int di, float v) {
-        d.diag_last[di] = v;
+        dlast[di] = v;
         if (loop_pos == 0) d.diag_first[di] = v;
         if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
     };
@@ -1315,11 +1337,18 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     // writer of weights, Adam state, targets and the entropy coefficient, applies NOTHING
     const unsigned aborted = T.abort ? sload(T.abort) : 0u;
 
-    if ((int)blockIdx.x < T.njobs) {
+    // block 0: the step's diagnostics (dispatched first: it is the longest block of the launch); blocks 1 .. njobs: tiles.
+    // Diagnostics go to the mapped pinned host buffer only on the steps whose caller reads them (sa.pad2 bit 1: the last
+    // step of a loop, single steps) -- a store over the link on every step costs the launch ~1 us at its end -- and to a
+    // device scratch otherwise (diag_first: the first step of a loop, always host).
+    float *const dlast = (sa.pad2 & 2u) ? d.diag_last : d.diag_dev;
+    const bool keep_grad = (sa.pad2 & 2u) != 0;      // the flat gradient copies (sac_debug_fetch "g_*") follow the same rule
+    const int jb = (int)blockIdx.x - 1;
+    if (jb >= 0) {
         STAMP(4, 0);
         int li = 0;
 #pragma unroll
-        for (int q = 1; q < NDW; ++q) li = ((int)blockIdx.x >= T.job0[q]) ? q : li;
+        for (int q = 1; q < NDW; ++q) li = (jb >= T.job0[q]) ? q : li;
         // the layer descriptor through the scalar cache (uniform index): one s_load burst, no vector
         // load + readfirstlane round trip in front of the operand loads
         union { DwLayer J; unsigned long long w[sizeof(DwLayer) / 8]; } ud;
@@ -1334,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         { unsigned long long probe = ud.w[0]; asm volatile("" :: "s"(probe)); }
         STAMP(4, 3);
 #endif
-        const int jj = blockIdx.x - J.job0;
+        const int jj = jb - J.job0;
         const int n0 = 16 * (jj / J.nk), k0 = 64 * (jj % J.nk);
         // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
         const int k_own = k0 + 16 * wave + r;
@@ -1436,20 +1465,22 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
                     p4[i] = p; m4[i] = m; v4[i] = v;
                     const size_t o = frag_off(n, k_own, J.ldp);
                     J.P[o] = p;
-                    if (J.G) J.G[o] = gsum[i];
+                    if (J.G && keep_grad) J.G[o] = gsum[i];
                     if (polyak) J.TP[o] = tp4[i] * (1.0f - d.tau) + p * d.tau;
                 }
             }
-            st4(J.PT + ot, p4);
-            st4(J.MT + ot, m4);
-            st4(J.VT + ot, v4);
+            // 16-B stores of the launch's ~4 MB of new state go out write-through (sc1): plain stores would sit dirty in
+            // the L2s until the end-of-kernel write-back, in front of the next launch
+            st4_sc1(J.PT + ot, p4);
+            st4_sc1(J.MT + ot, m4);
+            st4_sc1(J.VT + ot, v4);
         }
         if (bias_lane) {
             const int n = n0 + threadIdx.x;
             const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
             adam_update(pb, mbv, vbv, gb, step_size, bc2s);
             J.bias[n] = pb; J.mb[n] = mbv; J.vb[n] = vbv;
-            if (J.gb) J.gb[n] = gb;
+            if (J.gb && keep_grad) J.gb[n] = gb;
             if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
         STAMP(4, 2);
@@ -1540,7 +1571,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             const float o4[4] = {(float)mean, (float)sqrt(var), (float)MX, (float)MN};
             for (int u = 0; u < 4; ++u) {
                 const int di = SAC_D_Q1_MEAN + 4 * q + u;
-                d.diag_last[di] = o4[u];
+                dlast[di] = o4[u];
                 if (loop_pos == 0) d.diag_first[di] = o4[u];
                 if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = o4[u];
             }
@@ -1560,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             }
             else if (q == 5) { v = alpha_loss; di = SAC_D_ALPHA_LOSS; }
             else { di = 30 + (q - 6); }
-            d.diag_last[di] = v;
+            dlast[di] = v;
             if (loop_pos == 0) d.diag_first[di] = v;
             if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
         }
@@ -1609,6 +1640,7 @@ struct sac_trainer {
     bool fused = false;
     unsigned fused_seq = 0;                           // launches so far: the hand-off counters count in units of it
     unsigned fused_unchecked = 0;                     // fused launches since the host last looked at the abort marker
+    bool publish_diag = true;                         // the next step's diagnostics go to the pinned host buffer (its caller reads them)
     unsigned test_stall_at = 0;                       // SAC_FUSED_TEST_STALL=<n>: the n-th fused launch loses a producer (tests)
     void (*abc)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_abc = 0;
@@ -1721,6 +1753,9 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
     const double tq = (double)(t->adam_t + 1), tp = (double)(t->adam_t_pi + 1);
     StepArg sq{t->n_train_steps_total, t->adam_t + 1, j, 1, 1.0 - std::pow(0.9, tq), std::sqrt(1.0 - std::pow(0.999, tq))};
     StepArg sp{t->n_train_steps_total, t->adam_t_pi + 1, j, 2, 1.0 - std::pow(0.9, tp), std::sqrt(1.0 - std::pow(0.999, tp))};
+    // (TD3's diagnostics vector is filled by two launches and its policy half only on policy steps: every step goes to the
+    //  host buffer, so "last" keeps meaning the most recent value of each entry)
+    sq.pad2 = sp.pad2 = 2u;
     hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
     hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
     hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
@@ -1757,12 +1792,13 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     const int NB = t->NB;
     const double tt = (double)(t->adam_t + 1);
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
+    sa.pad2 = t->publish_diag ? 2u : 0u;
     const int SPv = t->SP;
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
     if (t->fused) {
         // two launches: A + B + C as k_abc (in-launch hand-offs), then the weight-gradient / Adam launch
         sa.seq = ++t->fused_seq;
-        sa.pad2 = (t->test_stall_at && sa.seq == t->test_stall_at) ? 1u : 0u;
+        sa.pad2 |= (t->test_stall_at && sa.seq == t->test_stall_at) ? 1u : 0u;
         t->fused_unchecked += 1;
         FusedGate &G = g_gate[t->device & 63];
         {
@@ -1939,7 +1975,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
     arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
-    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (3 * t->NB + 2);     // head[2][NB], phase-B[NB], log-pi, abort
+    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (5 * t->NB + 2);     // head[2][NB], qa / tq / ac [NB], log-pi, abort
     arena.reserve(reinterpret_cast<void **>(&t->d_sync), t->sync_bytes);
     arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW * 3);
     g_arena = nullptr;
@@ -1960,9 +1996,10 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     for (int i = 0; i < 3; ++i) d.PT[i] = t->net[i].PT;
     for (int l = 0; l < 3; ++l) { d.LP[l] = t->net[0].L[l]; d.LQ[l] = t->net[1].L[l]; }
     d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
+    d.diag_dev = t->d_diag;
     d.eps1 = d.eps2 = nullptr;
     d.cnt = t->d_sync;
-    d.abort_flag = t->d_sync + (size_t)CNT_STRIDE * (3 * t->NB + 1);
+    d.abort_flag = t->d_sync + (size_t)CNT_STRIDE * (5 * t->NB + 1);
 
     // weight-gradient work tables: the 256x256 layers first (longest jobs).  SAC: one table (3 nets).  TD3: the two
     // critics without / with the Polyak targets (the soft update follows the critics' step on policy steps only),
@@ -2268,7 +2305,10 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     hipStream_t s = t->stream;
     SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[slot], 0));
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    if (launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr)) return -1;
+    t->publish_diag = diag != nullptr;
+    const int rc_step = launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr);
+    t->publish_diag = true;
+    if (rc_step) return -1;
     SAC_HIP(hipEventRecord(b->ring_free[slot], s));
     b->ring_in_use[slot] = true;
     t->mirror_valid = false;
@@ -2326,8 +2366,11 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[2], b->stream));
         SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
         SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0));
-        for (int64_t i = 0; i < m; ++i)
+        for (int64_t i = 0; i < m; ++i) {
+            t->publish_diag = (first + i == n_steps - 1);
             if (launch_step(t, b->d_slots + (size_t)(pos + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
+        }
+        t->publish_diag = true;
         SAC_HIP(hipEventRecord(t->ev_done[e], s));
         SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV, "internal: loop chunk bookkeeping overflow");
         live[n_live++] = Live{pos, m, e};
@@ -2358,8 +2401,11 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     constexpr int NE = 7;            // e0 A e1 B e2 C e3 (nothing) e4 D e5 (nothing) e6
     std::vector<hipEvent_t> ev((size_t)n_steps * NE);
     for (auto &e : ev) SAC_HIP(hipEventCreate(&e));
-    for (int64_t i = 0; i < n_steps; ++i)
+    for (int64_t i = 0; i < n_steps; ++i) {
+        t->publish_diag = (i == n_steps - 1);
         if (launch_step(t, b->d_slots + (size_t)i * b->slot.slot_floats, b->slot, (int)i, &ev[(size_t)i * NE])) return -1;
+    }
+    t->publish_diag = true;
     SAC_HIP(hipStreamSynchronize(s));
     if (check_fused_abort(t)) return -3;
     // interval k = launch k between two event records; the empty interval e5->e6 measures what an

@@ -21,7 +21,7 @@ for sel, name in ((lambda b: (b & 7) < 4, "critic chain"), (lambda b: (b & 7) in
                   (lambda b: (b & 7) in (6, 7), "policy chain s'")):
     bl = [b for b in blocks if sel(b)]
     ww = w[bl]
-    ns = 10 if name != "policy chain s'" else 8
+    ns = 10
     med = [np.median(ww[:, i] - t0) / 100.0 for i in range(ns)]
     mx = [(ww[:, i].max() - t0) / 100.0 for i in range(ns)]
     print(f"{name} n={len(bl)}")
