@@ -347,6 +347,13 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(cnt_lp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // critic chain: the transposed W2 slice of the critic backward (phase C) is requested HERE, in front of the actor
+    // tail -- it depends on no hand-off, and its first eight k-chunks land while the tail runs
+    WRing<1, 8> rc;
+    if (isq) {
+        rc.init(d.PT[1 + net] + d.LQ[1].offWt, H, n0, 16);
+        rc.fill(H >> 4);
+    }
     if (isq) {
         // ---- actor path: UNIT input gradient of Q_i(s, a_new) (dq = 1), partial over this block's columns ----
 #pragma unroll
@@ -398,7 +405,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         lds_barrier();
         if (!s_ok) return;
         STAMP(0, 8);
-        WRing<1, 8> rc;
         const float wk = P[d.LQ[2].offW + frag_off(0, k, H)];
         const float b3a = sload(d.P[3] + oB3), b3b = sload(d.P[4] + oB3), b3q = sload(P + oB3);
         float qa[SP], qb[SP], qq[SP], in_c = 0.f, in_r = 0.f, in_t = 0.f;
@@ -420,10 +426,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + frag_off(k, row0 + 4 * qd, B));
         f32x4 h1v[1];
         h1v[0] = ld4(h1T + frag_off(n0 + c, row0 + 4 * g, B));
-        SB();
-        rc.init(PT + d.LQ[1].offWt, H, n0, 16);              // (needed behind dq -> dL/dh2: requested behind the small loads)
-        rc.fill(H >> 4);
-        SB();
         const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
         if (threadIdx.x < RB) {
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             s_dq[threadIdx.x] = dq;
         }
         lds_barrier();
+        STAMP(1, 0);
         // dL/dh2 = dq * w3 * relu'(h2)   (thread = feature k, 4-row groups); kept for dW by the owner block
         f32x4 gv2[4];
 #pragma unroll
@@ -450,9 +453,13 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             }
         }
         lds_barrier();
+        STAMP(1, 1);
         {   // dL/dh1[:, this block's features] = (dL/dh2 . W2)[:, slice] * relu'(h1)
             f32x4 acc[1] = {};
             gemm_ring(rc, X2, H, H >> 4, acc);
+#ifdef SAC_STAMPS
+            { float probe = acc[0][0]; asm volatile("" ::"v"(probe)); STAMP(1, 2); }
+#endif
             if (threadIdx.x < RB && part == 0) {
                 const int r = row0 + threadIdx.x;
                 d.q[(size_t)net * B + r] = vq;

@@ -1328,7 +1328,7 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
 __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
-    __shared__ float redb[4 * 16];
+    __shared__ __attribute__((aligned(16))) float redb[4 * 16 * 2];
     const int B = d.B;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -1345,7 +1345,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     const bool keep_grad = (sa.pad2 & 2u) != 0;      // the flat gradient copies (sac_debug_fetch "g_*") follow the same rule
     const int jb = (int)blockIdx.x - 1;
     if (jb >= 0) {
-        STAMP(4, 0);
+        STAMP(4 - 2 * (sa.loop_pos & 1), 0);
         int li = 0;
 #pragma unroll
         for (int q = 1; q < NDW; ++q) li = (jb >= T.job0[q]) ? q : li;
@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             if (J.gb && keep_grad) J.gb[n] = gb;
             if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
         }
-        STAMP(4, 2);
+        STAMP(4 - 2 * (sa.loop_pos & 1), 2);
     } else if (aborted) {
         // tell the host which launch was the first one not applied (diagnostic slots 30 / 31 are unused)
         if (threadIdx.x == 0 && d.diag_last[31] == 0.f) { d.diag_last[30] = __builtin_bit_cast(float, sa.seq); d.diag_last[31] = 1.f; }
@@ -1507,27 +1507,49 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         SB();
         const AlphaStep as = alpha_step(cp, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s);
         const float alpha = as.alpha, alpha_loss = as.alpha_loss;
-        double sm[NSTAT], sq[NSTAT], ls4[4];
-        float mx[NSTAT], mn[NSTAT];
-#pragma unroll
-        for (int q = 0; q < NSTAT; ++q) { sm[q] = 0; sq[q] = 0; mx[q] = -INFINITY; mn[q] = INFINITY; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ls4[q] = 0;
-        auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
+#ifdef SAC_STAMPS
+        { float probe = alpha; asm volatile("" ::"v"(probe)); STAMP(3, 2); }
+        { float probe = ls0[3][3] + yv0; asm volatile("" ::"v"(probe)); STAMP(3, 3); }
+#endif
+        // Reduction: a row contributes 16 per-row quantities (below); they go to LDS as a [16][256] float panel, and 16
+        // groups of 16 lanes reduce one quantity each in double -- 16 LDS reads and four 16-lane shuffle levels per lane.
+        // (A full-wave butterfly over 28 per-thread partials, most of them doubles, cost 264 ds_bpermute per lane: 3.6 us.)
+        //   0 q1  1 q2  2 y  3 log_pi (each: sum, sum of squares, max, min)   4 (q1-y)^2  5 (q2-y)^2  6 log_pi - q_new
+        //   7 alpha log_pi - q_new (sums)   8 sum mu  9 sum mu^2  10 max mu  11 min mu  12-15 the same for log_std
+        float *panel = red;                                   // [16][256]
+        const int qd = threadIdx.x >> 4, pl = threadIdx.x & 15;   // this lane's quantity / its share of the rows
+        double r_s = 0, r_s2 = 0;
+        float r_mx = -INFINITY, r_mn = INFINITY;
         for (int i0 = 0; i0 < Bt; i0 += 256) {
             const int i = i0 + threadIdx.x;
-            if (i < Bt) {
+            {
                 const float e1 = q10 - yv0, e2 = q20 - yv0;
                 const float qn = fminf(qa0, qb0);
-                ls4[0] += (double)e1 * e1; ls4[1] += (double)e2 * e2;
-                ls4[2] += (double)(lp0 - qn); ls4[3] += (double)(alpha * lp0 - qn);
-                acc1(0, q10); acc1(1, q20); acc1(2, yv0); acc1(3, lp0);
+                // the row's <= 16 values of mu / log_std: sums in float (seven to sixteen terms per row)
+                float s_mu = 0.f, s_mu2 = 0.f, s_ls = 0.f, s_ls2 = 0.f, mx_mu = -INFINITY, mn_mu = INFINITY, mx_ls = -INFINITY, mn_ls = INFINITY;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        if (4 * j + u < d.A) { acc1(4, mu0[j][u]); acc1(5, ls0[j][u]); }
+                        if (4 * j + u < d.A) {
+                            const float m_ = mu0[j][u], l_ = ls0[j][u];
+                            s_mu += m_; s_mu2 += m_ * m_; mx_mu = fmaxf(mx_mu, m_); mn_mu = fminf(mn_mu, m_);
+                            s_ls += l_; s_ls2 += l_ * l_; mx_ls = fmaxf(mx_ls, l_); mn_ls = fminf(mn_ls, l_);
+                        }
+                const float vals[16] = {q10, q20, yv0, lp0, e1 * e1, e2 * e2, lp0 - qn, alpha * lp0 - qn,
+                                        s_mu, s_mu2, mx_mu, mn_mu, s_ls, s_ls2, mx_ls, mn_ls};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) panel[q * 256 + threadIdx.x] = vals[q];
             }
+            lds_barrier();
+            const int nrow = (Bt - i0 < 256) ? Bt - i0 : 256;
+            for (int rr = pl; rr < nrow; rr += 16) {
+                const float v = panel[qd * 256 + rr];
+                r_s += (double)v;
+                r_s2 += (double)v * (double)v;              // (used for quantities 0-3 only)
+                r_mx = fmaxf(r_mx, v); r_mn = fminf(r_mn, v);
+            }
+            lds_barrier();                                    // panel free for the next pass
             if (i0 + 256 < Bt) {             // batches above 256 rows: the next pass's row
                 const int n = (i + 256 < Bt) ? i + 256 : 0;
                 yv0 = d.y[n]; q10 = d.q[n]; q20 = d.q[(size_t)B + n]; lp0 = d.logpi[n];
@@ -1537,33 +1559,22 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int q = 0; q < NSTAT; ++q) {
-                sm[q] += __shfl_xor(sm[q], o); sq[q] += __shfl_xor(sq[q], o);
-                mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o)); mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ls4[q] += __shfl_xor(ls4[q], o);
+        for (int o = 8; o > 0; o >>= 1) {
+            r_s += __shfl_xor(r_s, o); r_s2 += __shfl_xor(r_s2, o);
+            r_mx = fmaxf(r_mx, __shfl_xor(r_mx, o)); r_mn = fminf(r_mn, __shfl_xor(r_mn, o));
         }
-        double *sh = reinterpret_cast<double *>(red);      // [4 waves][32]
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NSTAT; ++q) {
-                sh[wave * 32 + q] = sm[q]; sh[wave * 32 + 6 + q] = sq[q];
-                sh[wave * 32 + 12 + q] = mx[q]; sh[wave * 32 + 18 + q] = mn[q];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sh[wave * 32 + 24 + q] = ls4[q];
-        }
+#ifdef SAC_STAMPS
+        { float probe = (float)r_s; asm volatile("" ::"v"(probe)); STAMP(3, 4); }
+#endif
+        double *tot = reinterpret_cast<double *>(redb);      // [16 quantities] x {sum, sum of squares, max, min}: 512 B
+        if (pl == 0) { tot[qd * 4 + 0] = r_s; tot[qd * 4 + 1] = r_s2; tot[qd * 4 + 2] = r_mx; tot[qd * 4 + 3] = r_mn; }
         lds_barrier();
+        STAMP(3, 5);
         if (threadIdx.x < NSTAT) {
-            const int q = threadIdx.x;
-            double s = 0, s2 = 0, MX = -INFINITY, MN = INFINITY;
-            for (int w = 0; w < 4; ++w) {
-                s += sh[w * 32 + q]; s2 += sh[w * 32 + 6 + q];
-                MX = fmax(MX, sh[w * 32 + 12 + q]); MN = fmin(MN, sh[w * 32 + 18 + q]);
-            }
+            const int q = threadIdx.x;               // q1, q2, q_target, log_pi | mu, log_std
+            double s, s2, MX, MN;
+            if (q < 4) { s = tot[q * 4]; s2 = tot[q * 4 + 1]; MX = tot[q * 4 + 2]; MN = tot[q * 4 + 3]; }
+            else { const int b0 = 8 + 4 * (q - 4); s = tot[b0 * 4]; s2 = tot[(b0 + 1) * 4]; MX = tot[(b0 + 2) * 4 + 2]; MN = tot[(b0 + 3) * 4 + 3]; }
             const double cnt = (q < 4) ? (double)Bt : (double)Bt * d.A;
             const double mean = s / cnt;
             double var = s2 / cnt - mean * mean;
@@ -1580,9 +1591,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
             float v = 0.f;
             int di = SAC_D_QF1_LOSS + q;
             if (q < 4) {
-                double s = 0;
-                for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24 + q];
-                v = (float)(s / Bt);
+                v = (float)(tot[(4 + q) * 4] / Bt);
             } else if (q == 4) {
                 v = alpha; di = SAC_D_ALPHA;
                 Ctl *cw = d.ctl;                   // the step's only writer of the entropy-coefficient state

@@ -37,3 +37,20 @@ w3 = st[3]
 b3 = [b for b in range(512) if w3[b, 0] > 0]
 if b3 and b4:
     print("diagnostics block: starts", (w3[b3[0], 0] - t4) / 100.0, "after the first dW block, ends", (w3[b3[0], 1] - t4) / 100.0)
+# k_dw_adam alternates between stamp slots 4 (even loop positions) and 2 (odd): the last step of the 200-step loop is odd
+wl, wp = st[2], st[4]          # last step's D, the one before
+bl = [b for b in range(512) if wl[b, 0] > 0]; bp = [b for b in range(512) if wp[b, 0] > 0]
+if bl and bp:
+    print("previous k_dw_adam: last tile block ends %.2f us before this k_abc's first block starts; its first block started %.2f us before"
+          % ((t0 - wp[bp][:, 2].max()) / 100.0, (t0 - min(wp[b, 0] for b in bp)) / 100.0))
+    print("this step: k_abc first start -> k_dw_adam first start %.2f us; k_dw_adam tiles end %.2f us after its first start"
+          % ((min(wl[b, 0] for b in bl) - t0) / 100.0, (wl[bl][:, 2].max() - min(wl[b, 0] for b in bl)) / 100.0))
+w1 = st[1]
+b1 = [b for b in blocks if (b & 7) < 4 and w1[b, 0] > 0]
+if b1:
+    print("critic phase C (median, after C wait over): dq ready %.2f  dL/dh2 in LDS %.2f  slice GEMM done %.2f  end %.2f"
+          % (tuple(np.median(w1[b1][:, i] - w[b1][:, 8]) / 100.0 for i in range(3)) + (np.median(w[b1][:, 9] - w[b1][:, 8]) / 100.0,)))
+if b3:
+    dd = st[3][b3[0]]
+    print("diagnostics block: alpha %.2f  loads %.2f  accumulated+shuffled %.2f  after barrier %.2f  end %.2f (us after its start)"
+          % tuple((dd[i] - dd[0]) / 100.0 for i in (2, 3, 4, 5, 1)))
