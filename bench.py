@@ -118,8 +118,9 @@ def measure_peaks(device):
     out = (C.c_float * 4)()
     _lib.check(_lib.load().sac_measure_peaks(int(device), out), "sac_measure_peaks")
     return dict(hbm_copy_gbs=round(float(out[0]), 1), fp32_mfma_tflops=round(float(out[1]), 2),
-                how="float4 stream copy of 1 GiB (read + write, best of 5 passes); back-to-back "
-                    "v_mfma_f32_16x16x4_f32 on 8 independent accumulators, one wave per SIMD x 4 (best of 3)")
+                how="float4 stream copy of 1 GiB (read + write; 16-KB tiles per workgroup, best of 6 passes over three grid "
+                    "sizes); back-to-back v_mfma_f32_16x16x4_f32 on 8 independent accumulators, one and four waves per "
+                    "SIMD (best of 4 passes)")
 
 
 def cpu_baseline(O, A, B, n_host=1_000_000, budget_s=26.0):
@@ -489,7 +490,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
     dom_ms = prof[dom] + boundary_ms
     achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic(dom, workload_tag(task, B))
+    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc"}.get(dom, dom), workload_tag(task, B))
     pk_m = peaks["fp32_mfma_tflops"] if peaks else None
     whole = sum(fl.values()) * value / world / 1e12
     out["roofline"] = dict(

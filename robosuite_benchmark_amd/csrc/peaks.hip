@@ -7,15 +7,16 @@ namespace sac {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// float4 copy, 16 B per lane, 1 KB per wave-instruction, four independent loads in flight per lane (read + write counted)
+// float4 copy (read + write counted): a workgroup moves 16-KB tiles -- four 1-KB wave-instructions per wave in flight,
+// each lane 16 B -- dealt round-robin over the grid
 __global__ __launch_bounds__(256) void k_peak_copy(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, size_t n4) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = e;
+    const size_t tiles = n4 / 1024;                              // 1024 float4 = 16 KB
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const f32x4 *s = src + t * 1024 + threadIdx.x;
+        f32x4 *o = dst + t * 1024 + threadIdx.x;
+        const f32x4 a = s[0], b = s[256], c = s[512], e = s[768];
+        o[0] = a; o[256] = b; o[512] = c; o[768] = e;
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 // back-to-back v_mfma_f32_16x16x4_f32 on 8 independent accumulators per wave, operands in registers (non-trivial
@@ -51,7 +52,6 @@ extern "C" int sac_measure_peaks(int device, float out[4]) {
     int rc = 0;
     float *src = nullptr, *dst = nullptr, *mo = nullptr;
     const size_t bytes = (size_t)1 << 30;                      // 1 GiB each way: four times the 256-MiB Infinity Cache
-    const int grid = 256 * 8;                                  // 8 workgroups per CU
     do {
         if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess ||
             hipMalloc(&mo, sizeof(float) * 1024 * 256) != hipSuccess) {
@@ -62,9 +62,10 @@ extern "C" int sac_measure_peaks(int device, float out[4]) {
         (void)hipMemsetAsync(src, 0x3c, bytes, s);
         (void)hipMemsetAsync(dst, 0, bytes, s);
         float best_copy = 0.f;
-        for (int rep = 0; rep < 6; ++rep) {
+        const int grids[3] = {256 * 8, 256 * 16, 256 * 32};
+        for (int rep = 0; rep < 7; ++rep) {
             (void)hipEventRecord(e0, s);
-            hipLaunchKernelGGL(k_peak_copy, dim3(grid), dim3(256), 0, s, (const f32x4 *)src, (f32x4 *)dst, bytes / 16);
+            hipLaunchKernelGGL(k_peak_copy, dim3(grids[rep % 3]), dim3(256), 0, s, (const f32x4 *)src, (f32x4 *)dst, bytes / 16);
             (void)hipEventRecord(e1, s);
             if (hipStreamSynchronize(s) != hipSuccess) { sac::set_error("sac_measure_peaks: copy kernel failed"); rc = -1; break; }
             float ms = 0.f;
@@ -74,8 +75,9 @@ extern "C" int sac_measure_peaks(int device, float out[4]) {
         }
         if (rc) break;
         float best_mfma = 0.f, mfma_ms = 0.f;
-        const int iters = 20000, wgs = 1024;                   // 4 workgroups per CU = 4 waves per SIMD-set ... one per SIMD each
-        for (int rep = 0; rep < 4; ++rep) {
+        // (one and four waves per SIMD; the chip settles on its clock under load within the first pass)
+        for (int rep = 0; rep < 5; ++rep) {
+            const int wgs = (rep & 1) ? 256 : 1024, iters = (rep & 1) ? 60000 : 20000;
             (void)hipEventRecord(e0, s);
             hipLaunchKernelGGL(k_peak_mfma, dim3(wgs), dim3(256), 0, s, mo, iters, 0.5f + 0.1f * rep);
             (void)hipEventRecord(e1, s);

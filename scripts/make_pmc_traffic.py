@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Combine the per-kernel PMC summaries (scripts/summarize_pmc.py output of the FETCH_SIZE, WRITE_SIZE and
 MFMA passes) into profiles/<tag>_pmc_traffic.json, the file bench.py reads `roofline.traffic` from.
-    python scripts/make_pmc_traffic.py fetch.json write.json mfma.json > profiles/r01_e_pmc_traffic.json
+    python scripts/make_pmc_traffic.py fetch.json write.json mfma.json lift_b256 > profiles/r02_lift_b256_pmc_traffic.json
 Corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): counters are KiB; gfx950 tallies a 128-B request
 at 64 B, so FETCH_SIZE is doubled for the kernels that stream 16 B per lane from contiguous segments (all
 step kernels); k_gather reads random 176-B rows with 64-B requests and its RAW counter matches the known
@@ -10,7 +10,8 @@ import json
 import sys
 
 fetch, write, mfma = (json.load(open(p)) for p in sys.argv[1:4])
-out = {"_note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "kernels": {}}
+workload = sys.argv[4] if len(sys.argv) > 4 else "lift_b256"      # bench.py looks its workload's summary up by this tag
+out = {"_note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "workload": workload, "kernels": {}}
 for k in sorted(fetch):
     name = k.split("<")[0].split("::")[-1]
     f = fetch[k].get("FETCH_SIZE", {}).get("mean_per_launch")

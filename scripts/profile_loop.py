@@ -15,9 +15,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--buffer", type=int, default=1_000_000)
-    ap.add_argument("--task", type=int, default=0)
+    ap.add_argument("--task", type=str, default="Lift")
     args = ap.parse_args()
-    task, O, A = bench.parallel.SWEEP[args.task]
+    task, O, A = next(t for t in bench.parallel.SWEEP + bench.EXTRA_TASKS if t[0] == args.task)
     trainer, buf = bench.build_replica(task, O, A, args.batch, args.buffer, seed=17, device=0)
     trainer.train_loop(buf, 50, batch_size=args.batch)
     first, last = trainer.train_loop(buf, args.steps, batch_size=args.batch)
