@@ -259,12 +259,20 @@ def td3_main(args):
     print(json.dumps(out), flush=True)
 
 
-def concurrent_replicas(task, O, A, B, n_replicas, steps, device):
+def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False):
     """Extra data point, never `value`: R independent runs (own buffer, nets, streams) driven from R host threads
     on ONE GPU -- the reference's real workload is 5 seeds x 29 configurations of independent jobs
     (/root/reference/launch_jobs.sh:15-24), and a single batch-256 run leaves most of the chip idle."""
     import threading
+    # co-tenant runs: the fused step needs the whole chip to itself, so the replicas take the four-launch step
+    os.environ["SAC_FUSED"] = "0"
     reps = [build_replica(task, O, A, B, 100_000, 100 + i, device) for i in range(n_replicas)]
+    os.environ.pop("SAC_FUSED", None)
+    if by_xcd:          # experiment: replica i confined to the 32 CUs of XCD i % 8 (CU-masked streams)
+        from robosuite_benchmark_amd import _lib
+        for i, (tr, buf) in enumerate(reps):
+            _lib.check(tr._lib.sac_trainer_set_xcd(tr._h, i % 8), "sac_trainer_set_xcd")
+            _lib.check(tr._lib.sac_buffer_set_xcd(buf._h, i % 8), "sac_buffer_set_xcd")
     for tr, buf in reps:
         tr.train_loop(buf, 100, batch_size=B)
     t0 = time.perf_counter()
@@ -275,7 +283,8 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device):
         t.join()
     el = time.perf_counter() - t0
     return dict(replicas=n_replicas, steps_each=steps, value=round(n_replicas * steps / el, 2), unit="grad-steps/s",
-                note="aggregate of independent runs sharing one GPU (100000-slot buffers); not the headline metric")
+                placement="one XCD (32 CUs) per replica, CU-masked streams" if by_xcd else "every launch spans the chip",
+                note="aggregate of independent runs sharing one GPU (100000-slot buffers, four-launch step); not the headline metric")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -363,6 +372,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=500)
     ap.add_argument("--agent", type=str, default="SAC", choices=["SAC", "TD3"],
                     help="TD3: the SURVEY 8f row on the same workload shape (N=1, its own JSON line); default SAC = the headline metric")
+    ap.add_argument("--xcd-replicas", action="store_true", help="with --replicas-per-gpu: confine replica i to XCD i % 8")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="N=1 only: also time R concurrent independent runs on the GPU (reported beside, never as, value)")
     args = ap.parse_args()
@@ -469,7 +479,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     fl_all = flops_per_kernel(B, O, A)
     step_kernels = [k for k in prof if k.startswith("k_") and k not in ("k_gather", "k_mt_randint") and prof[k] > 0]
     # a fused launch carries the FLOPs of the launches it replaces ("k_fwd_abc" = a + b + c ...)
-    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_fwd_bc": ("k_fwd_b", "k_bwd")}
+    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_step": ("k_fwd_a", "k_fwd_b", "k_bwd", "k_dw_adam")}
     fl = {k: (sum(fl_all[p] for p in fused_parts[k]) if k in fused_parts else fl_all[k]) for k in step_kernels}
     kern = {}
     for k, f in fl.items():
@@ -490,7 +500,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
     dom_ms = prof[dom] + boundary_ms
     achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc"}.get(dom, dom), workload_tag(task, B))
+    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc", "k_step": "k_abc"}.get(dom, dom), workload_tag(task, B))
     pk_m = peaks["fp32_mfma_tflops"] if peaks else None
     whole = sum(fl.values()) * value / world / 1e12
     out["roofline"] = dict(
@@ -569,7 +579,8 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
                              note="sac_buffer_add_f64 of one epoch's exploration steps: pack into pinned staging + enqueue "
                                   "(call returns) vs rows resident in HBM")
     if world == 1 and args.replicas_per_gpu > 1:
-        out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device)
+        out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device,
+                                                         by_xcd=args.xcd_replicas)
     return out
 
 

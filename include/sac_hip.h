@@ -238,6 +238,13 @@ int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float 
  * and the wall ms of all n_steps steps}.  n_steps <= 4096. */
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float out_ms[9]);
 
+/* Experiment hooks (bench.py --replicas-per-gpu R --xcd-replicas): confine a handle's launches to
+ * the CUs of one XCD (0..7) through a CU-masked stream, so that eight independent runs -- the reference's real workload is
+ * many independent jobs, /root/reference/launch_jobs.sh:15-24 -- can share one GPU without each launch spanning the chip.
+ * A trainer confined this way takes the four-launch step (the fused step needs every CU). */
+int sac_buffer_set_xcd(sac_buffer_t *buf, int xcd);
+int sac_trainer_set_xcd(sac_trainer_t *t, int xcd);
+
 /* SURVEY.md 8d "Bounding roofline": the peaks the roofline fractions divide by, MEASURED on the box -- a float4
  * stream copy of 1 GiB (read + write GB/s) and a back-to-back v_mfma_f32_16x16x4_f32 loop on every SIMD (TFLOP/s).
  * out[4] = {copy GB/s, fp32 MFMA TFLOP/s, GB moved per copy pass, ms of the best MFMA pass}. */

@@ -1227,8 +1227,6 @@ __global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S,
     }
 }
 
-#include "sac_fused.h"
-
 // ------------------------------------------------------------------------------------------
 // K5: weight gradients + Adam + Polyak, tile-owner parallel.  One WG owns a 16 (out) x 64 (in)
 // tile of one layer: dW = sum_b dY[b][n] X[b][k] with the batch split over the 4 waves (MFMA
@@ -1325,25 +1323,23 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
     }
 }
 
-__global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
-    kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
-    __shared__ __attribute__((aligned(16))) float redb[4 * 16 * 2];
+// The body of the weight-gradient / Adam launch for virtual block `vblock` (0: the step's diagnostics; 1 .. njobs: tile
+// owners).  (A function of its own since the one-launch experiment -- this body as a phase D of k_abc behind a grid-wide
+// counter hand-off: the hand-off took 6.5 us against ~3 us for the dispatch boundary plus start-up it replaced, DESIGN.md
+// section 7 -- and kept that way.)  red: 4096 floats, redb: 128 floats.
+__device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, const float *__restrict__ S, const StepArg &sa,
+                                             float *red, float *redb, int vblock, unsigned aborted) {
     const int B = d.B;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
     const Ctl *cp = d.ctl;
-    // fused step: the forward/backward launch gave up (a hand-off wait timed out) => this launch, the step's only
-    // writer of weights, Adam state, targets and the entropy coefficient, applies NOTHING
-    const unsigned aborted = T.abort ? sload(T.abort) : 0u;
-
     // block 0: the step's diagnostics (dispatched first: it is the longest block of the launch); blocks 1 .. njobs: tiles.
     // Diagnostics go to the mapped pinned host buffer only on the steps whose caller reads them (sa.pad2 bit 1: the last
     // step of a loop, single steps) -- a store over the link on every step costs the launch ~1 us at its end -- and to a
     // device scratch otherwise (diag_first: the first step of a loop, always host).
     float *const dlast = (sa.pad2 & 2u) ? d.diag_last : d.diag_dev;
     const bool keep_grad = (sa.pad2 & 2u) != 0;      // the flat gradient copies (sac_debug_fetch "g_*") follow the same rule
-    const int jb = (int)blockIdx.x - 1;
+    const int jb = vblock - 1;
     if (jb >= 0) {
         STAMP(4 - 2 * (sa.loop_pos & 1), 0);
         int li = 0;
@@ -1607,6 +1603,18 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
         STAMP(3, 1);
     }
 }
+
+__global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
+    kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
+    __shared__ __attribute__((aligned(16))) float redb[4 * 16 * 2];
+    // fused step: the forward/backward launch gave up (a hand-off wait timed out) => this launch, the step's only
+    // writer of weights, Adam state, targets and the entropy coefficient, applies NOTHING
+    const unsigned aborted = T.abort ? sload(T.abort) : 0u;
+    dw_adam_body(d, T, S, sa, red, redb, (int)blockIdx.x, aborted);
+}
+
+#include "sac_fused.h"
 
 }  // namespace sac
 
@@ -2448,6 +2456,27 @@ int sac_sync(sac_trainer_t *t) {
     SAC_HIP(hipSetDevice(t->device));
     SAC_HIP(hipStreamSynchronize(t->stream));
     return check_fused_abort(t);
+}
+
+// Experiment (bench.py --replicas-per-gpu with --xcd-replicas): confine this trainer's launches to one XCD's CUs.  The
+// fused step needs the whole chip, so the trainer switches to the four-launch step.
+extern "C" int sac_make_xcd_stream(hipStream_t *out, int xcd);
+int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
+    SAC_REQUIRE(t != nullptr, "null trainer");
+    SAC_HIP(hipSetDevice(t->device));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    hipStream_t ns = nullptr;
+    if (sac_make_xcd_stream(&ns, xcd)) return -1;
+    SAC_HIP(hipStreamDestroy(t->stream));
+    t->stream = ns;
+    if (t->fused) {
+        FusedGate &G = g_gate[t->device & 63];
+        std::lock_guard<std::mutex> lk(G.mu);
+        G.live -= 1;
+        t->fused = false;
+        t->dw.abort = nullptr;
+    }
+    return 0;
 }
 
 // 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step

@@ -175,12 +175,19 @@ class SACTrainer:
         self._host_policy_stale = True
         names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_bwd", "reserved", "k_dw_adam",
                  "event_pair", "steps_wall"]
-        if self.is_fused():          # the fused step: k_abc = launches A + B + C in one (the next two slots read 0)
+        mode = self.fused_mode()
+        if mode:                     # the fused step: k_abc = launches A + B + C in one (the next two slots read 0) ...
             names[2], names[3], names[4] = "k_fwd_abc", "fused_b", "fused_c"
+        if mode == 2:                # ... and, as the one-launch step, the weight-gradient / Adam phase as well
+            names[2], names[6] = "k_step", "fused_d"
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
+    def fused_mode(self):
+        """0: four launches per step; 1: k_abc + k_dw_adam; 2: one launch per step (k_abc with its phase D)."""
+        return int(self._lib.sac_trainer_is_fused(self._h)) if self._h is not None else 0
+
     def is_fused(self):
-        return bool(self._h is not None and self._lib.sac_trainer_is_fused(self._h))
+        return self.fused_mode() > 0
 
     def loop_timing_ms(self):
         v = [C.c_float() for _ in range(4)]

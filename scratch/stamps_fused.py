@@ -16,12 +16,13 @@ st = out.reshape(5, 512, 16).astype(np.int64)
 w = st[0]
 blocks = [b for b in range(512) if w[b, 0] > 0]
 t0 = min(w[b, 0] for b in blocks)
-names = ["start", "A done", "A published", "B wait over", "head done", "q partial out", "B done", "B published", "C wait over", "end"]
+names = ["start", "A done", "A published", "B wait over", "head done", "q partial out", "B done", "B published", "C wait over", "end",
+         "D wait over", "D done"]
 for sel, name in ((lambda b: (b & 7) < 4, "critic chain"), (lambda b: (b & 7) in (4, 5), "policy chain s"),
                   (lambda b: (b & 7) in (6, 7), "policy chain s'")):
     bl = [b for b in blocks if sel(b)]
     ww = w[bl]
-    ns = 10
+    ns = 12 if ww[:, 11].max() > 0 else 10
     med = [np.median(ww[:, i] - t0) / 100.0 for i in range(ns)]
     mx = [(ww[:, i].max() - t0) / 100.0 for i in range(ns)]
     print(f"{name} n={len(bl)}")
