@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -1646,7 +1647,7 @@ struct sac_trainer {
     Ctl *d_ctl = nullptr;
     void *h_stage = nullptr; size_t stage_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    static constexpr int NLOOP_EV = 8;
+    static constexpr int NLOOP_EV = 12;
     hipEvent_t ev_ready[NLOOP_EV] = {}, ev_done[NLOOP_EV] = {};                      // chunks of sac_train_loop in flight
     float *h_diag = nullptr, *d_diag_host = nullptr;  // mapped pinned: first[32] | last[32] (host view, device view)
     float last_ms[4] = {0, 0, 0, 0};
@@ -2345,8 +2346,34 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
 // index stream is one in-order sequence on the buffer's stream, so it consumes NumPy's generator exactly like
 // n_steps random_batch calls.
 constexpr int64_t LOOP_CH = 256, LOOP_RING = 2 * LOOP_CH;
+// Lengths of the first chunks (they sum to LOOP_CH, so every later chunk starts on a multiple of it).
+static const int64_t *loop_plan() {
+    static int64_t plan[8] = {4, 12, 48, 192, 0, 0, 0, 0};      // (1,3,12,48,192 and 2,6,24,96,128 measured the same within 1 %)
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (const char *e = getenv("SAC_CHUNK_PLAN")) {       // tuning experiments only: e.g. "4,12,48,192"
+            int64_t v[8] = {0}, sum = 0;
+            int n = 0;
+            for (const char *p = e; *p && n < 7; ++n) {
+                v[n] = strtoll(p, const_cast<char **>(&p), 10);
+                sum += v[n];
+                if (*p == ',') ++p;
+            }
+            if (sum == LOOP_CH) for (int i = 0; i < 8; ++i) plan[i] = v[i];
+        }
+    }
+    return plan;
+}
 static inline int64_t loop_chunk_len(int64_t done) {
-    return done == 0 ? 4 : (done == 4 ? 12 : (done == 16 ? 48 : (done == 64 ? 192 : LOOP_CH)));
+    if (done >= LOOP_CH) return LOOP_CH;
+    const int64_t *plan = loop_plan();
+    int64_t at = 0;
+    for (int i = 0; i < 8 && plan[i] > 0; ++i) {
+        if (done == at) return plan[i];
+        at += plan[i];
+    }
+    return LOOP_CH - done;
 }
 
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
@@ -2360,7 +2387,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
     if (ensure_idx(b, LOOP_RING * t->B)) return -1;
     struct Live { int64_t pos, m; int ev; };
-    Live live[sac_trainer::NLOOP_EV];
+    Live live[sac_trainer::NLOOP_EV + 4];
     int n_live = 0;
     SAC_HIP(hipEventRecord(t->ev[0], s));
     int64_t done = 0, pos = 0;
@@ -2389,12 +2416,18 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         }
         t->publish_diag = true;
         SAC_HIP(hipEventRecord(t->ev_done[e], s));
-        SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV, "internal: loop chunk bookkeeping overflow");
+        SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV + 4, "internal: loop chunk bookkeeping overflow");
         live[n_live++] = Live{pos, m, e};
         pos += m;
         done += m;
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
+    // The end of the loop is awaited by polling the last event for up to 2 ms (a user-space read of its signal) before
+    // the blocking wait: the runtime's own wake-up costs 10-20 us, a seventh of a 20-step call's fixed cost.
+    {
+        const auto spin_until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        while (hipEventQuery(t->ev[1]) == hipErrorNotReady && std::chrono::steady_clock::now() < spin_until) { }
+    }
     SAC_HIP(hipStreamSynchronize(s));             // (the diagnostics are in mapped pinned memory: nothing to copy)
     if (check_fused_abort(t)) return -3;
     if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
