@@ -119,7 +119,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     float *WL = red + FUSED_RED;         // [256][WLD]  critic chain: W2 slice, transposed (phase A -> phase B's tail)
     // XCD-aware map (speed only): b % 8 in {0,1} -> critic chain of Q1, {2,3} -> Q2, {4,5} -> policy chain on s (then T1,
     // then the policy backward), {6,7} -> policy chain on s' (then T2); the 16 blocks of row-block rb are 16 rb .. 16 rb + 15
-    const int xq = blockIdx.x >> 3, xr = blockIdx.x & 7;
+#ifndef SAC_XR_XOR
+#define SAC_XR_XOR 0
+#endif
+    const int xq = blockIdx.x >> 3, xr = (blockIdx.x & 7) ^ SAC_XR_XOR;      // (SAC_XR_XOR: placement experiments only)
     const bool isq = xr < 4;
     const int net = (xr >> 1) & 1;                            // critic chain: twin; policy chain: side
     const int bi = 2 * xq + (xr & 1);
@@ -320,12 +323,14 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         if (own_s) {
             if (a < A) {
                 d.mu[grow * 16 + a] = mean;
-                st_sc1(d.ls + grow * 16 + a, lstd);
-                st_sc1(d.lsok + grow * 16 + a, (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f);
+                d.ls[grow * 16 + a] = lstd;
                 d.z[grow * 16 + a] = zz;
-                st_sc1(d.epsv + grow * 16 + a, eps);
+                // what the policy backward of this row-block needs from the head, as ONE 16-byte write-through store per
+                // (row, action) -- four dword sc1 stores cost ~6x as much per byte, and this block is on the critical path
+                st4_sc1(d.hv4 + (size_t)(grow * 16 + a) * 4,
+                        f32x4{act, lstd, eps, (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.f : 0.f});
             }
-            st_sc1(d.anew + grow * 16 + a, act);             // (0 beyond A)
+            d.anew[grow * 16 + a] = act;                     // (0 beyond A)
             if (a == 0) d.logpi[grow] = lsum;
             if (threadIdx.x == 0) st_sc1(d.part_logpi + rb, lsum_blk);
         } else if (own_n) {
@@ -517,10 +522,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             qb[p] = ld_sc1(d.qpart2 + ((size_t)(3 * NB + rb) * SP + p) * 32 + row);
         }
         if (a < A) {
-            actv = ld_sc1(d.anew + gi);
 #pragma unroll
             for (int p = 0; p < 2 * SP; ++p) dap[p] = ld_sc1(d.dapart + (size_t)p * B * 16 + gi);
-            lsv = ld_sc1(d.ls + gi); epv = ld_sc1(d.epsv + gi); okv = ld_sc1(d.lsok + gi);
+            const f32x4 hv = ld4(d.hv4 + (size_t)gi * 4);     // (first touched here, behind the counter: exclusive 1-KB blocks)
+            actv = hv[0]; lsv = hv[1]; epv = hv[2]; okv = hv[3];
         }
         float qnew1 = 0.f, qnew2 = 0.f, dz = 0.f, dls = 0.f;
         {

@@ -106,6 +106,7 @@ struct Dev {
     // [row-block][32], hand-off counters (one per 128-B line: head[side][rb], phase-B-done[rb], log-pi partials) and
     // the sticky abort word (a wait timed out)
     float *qpart2, *logpi2p;
+    float *hv4;                    // fused step: {a_new, log_std, eps, clamp mask} of a (row, action) as ONE 16-byte value [B][16][4]
     unsigned *cnt, *abort_flag;
     // diagnostics
     float *diag_first, *diag_last, *diag_trace;      // first / last: mapped pinned host memory; trace: device
@@ -424,14 +425,31 @@ __device__ __forceinline__ void splitk_reduce(const f32x4 (&acc)[NTT], const flo
 #pragma unroll
     for (int t = 0; t < NTT; ++t) st4(red + ((wave * NTT + t) * 64 + lane) * 4, acc[t]);
     lds_barrier();
-    for (int e = threadIdx.x; e < NTT * 256; e += 256) {
-        const int t = e >> 8, l = (e >> 2) & 63, i = e & 3;
-        float s = 0.f;
+    if constexpr (SC1) {
+        // hand-off form (no bias): a thread sums four CONSECUTIVE columns of one row and publishes them with one 16-byte
+        // write-through store -- per byte a dword sc1 store costs ~6x a dwordx4 one, and a consumer block is waiting for these
+        for (int e = threadIdx.x; e < NTT * 64; e += 256) {
+            const int t = e >> 6, row = (e >> 2) & 15, c0 = 4 * (e & 3);
+            f32x4 s4;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[((w * NTT + t) * 64 + l) * 4 + i];
-        const int row = 4 * (l >> 4) + i, col = 16 * t + (l & 15);
-        if constexpr (SC1) st_sc1(out + row * ldo + col, s + (bias ? bias[col] : 0.f));
-        else out[row * ldo + col] = s + (bias ? bias[col] : 0.f);
+            for (int j = 0; j < 4; ++j) {
+                const int l = (row >> 2) * 16 + c0 + j, i = row & 3;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += red[((w * NTT + t) * 64 + l) * 4 + i];
+                s4[j] = s;
+            }
+            st4_sc1(out + row * ldo + 16 * t + c0, s4);
+        }
+    } else {
+        for (int e = threadIdx.x; e < NTT * 256; e += 256) {
+            const int t = e >> 8, l = (e >> 2) & 63, i = e & 3;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * NTT + t) * 64 + l) * 4 + i];
+            const int row = 4 * (l >> 4) + i, col = 16 * t + (l & 15);
+            out[row * ldo + col] = s + (bias ? bias[col] : 0.f);
+        }
     }
     lds_barrier();
 }
@@ -1982,7 +2000,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B}, {&d.QU, 2LL * H * B},
         {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
         {&d.headpart, 2LL * t->NB * 4 * RB * 32}, {&d.qpart, 6LL * 4 * B}, {&d.dapart, 2LL * 4 * B * 16},
-        {&d.qpart2, 6LL * t->NB * 4 * 32}, {&d.logpi2p, 32LL * t->NB},
+        {&d.qpart2, 6LL * t->NB * 4 * 32}, {&d.logpi2p, 32LL * t->NB}, {&d.hv4, 64LL * B},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
     long long tot = 0;
     for (auto &p : parts) tot += round_up64(p.second, 64);

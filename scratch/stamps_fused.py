@@ -55,3 +55,12 @@ if b3:
     dd = st[3][b3[0]]
     print("diagnostics block: alpha %.2f  loads %.2f  accumulated+shuffled %.2f  after barrier %.2f  end %.2f (us after its start)"
           % tuple((dd[i] - dd[0]) / 100.0 for i in (2, 3, 4, 5, 1)))
+# who is slow?  critic chain "B done" (stamp 6) and "A done" (stamp 1) by blockIdx % 8, by column part and by row-block
+import collections
+for st_i, nm in ((1, "A done"), (6, "B done"), (9, "end")):
+    for key, f in (("b%8", lambda b: b & 7), ("part", lambda b: (2 * (b >> 3) + (b & 1)) & 3), ("rb", lambda b: (2 * (b >> 3) + (b & 1)) >> 2)):
+        g = collections.defaultdict(list)
+        for b in blocks:
+            if (b & 7) < 4:
+                g[f(b)].append((w[b, st_i] - t0) / 100.0)
+        print(f"critic chain {nm:7s} by {key:5s}:", " ".join(f"{k}:{np.median(v):.2f}" for k, v in sorted(g.items())))
