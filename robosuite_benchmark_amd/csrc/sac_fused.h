@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // XCD-aware map (speed only): b % 8 in {0,1} -> critic chain of Q1, {2,3} -> Q2, {4,5} -> policy chain on s (then T1,
     // then the policy backward), {6,7} -> policy chain on s' (then T2); the 16 blocks of row-block rb are 16 rb .. 16 rb + 15
 #ifndef SAC_XR_XOR
-#define SAC_XR_XOR 0
+#define SAC_XR_XOR 4                 // blocks b % 8 in {0..3}: the policy chains (first link of the critical path: dispatched first)
 #endif
     const int xq = blockIdx.x >> 3, xr = (blockIdx.x & 7) ^ SAC_XR_XOR;      // (SAC_XR_XOR: placement experiments only)
     const bool isq = xr < 4;
@@ -139,14 +139,15 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const bool own_s = isq && net == 0 && part == 0, own_n = !isq && net == 0 && part == 0;
     // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
     // one producer block leaves without publishing, so its consumers run into the hand-off timeout
-    if ((sa.pad2 & 1u) && blockIdx.x == 4) return;
+    if ((sa.pad2 & 1u) && blockIdx.x == (4 ^ SAC_XR_XOR)) return;
     STAMP(0, 0);
-
     // =========================================================================================================
     // phase A
     // =========================================================================================================
+    float eps = 0.f;                     // the N(0,1) draw of phase B's rsample (made in phase A, below)
     f32x4 keep1[4], zkeep[4];
     float bv1[1], w3[4];
+    unsigned peek = 0u;                  // (thread 0 of a critic-chain block: early look at head[s][rb])
     {
         const float *P = isq ? d.P[1 + net] : d.P[0];
         const Layer L0 = isq ? d.LQ[0] : d.LP[0], L1 = isq ? d.LQ[1] : d.LP[1], L2 = isq ? d.LQ[2] : d.LP[2];
@@ -164,6 +165,15 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         SB();
         WRing<1, 8> r1;
         r1.init(P + L1.offW, H, n0, 16);
+        // The N(0,1) draw of phase B's rsample depends on nothing but (seed, step, row, action): it is computed HERE, behind
+        // the block's first requests, in the ~1.3 us it waits for their data anyway (in phase B it would sit on the
+        // critical path: the head partials are usually there before this chain is).
+        {
+            const int side0 = isq ? 0 : 1;
+            const float *epp0 = side0 ? d.eps2 : d.eps1;
+            if (a < A && !epp0) eps = philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side0 ? 1u : 0u);
+        }
+
         rows.commit(X0, KLQ, K0, O, d.KP, isq ? A : 0);
         lds_barrier();
         {   // first layer, all 256 features (recomputed by the 4 blocks of this row-block)
@@ -196,12 +206,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             else gemm_ring(r1, X1, H, H >> 4, acc);
             // feature-major copies: operands of the weight-gradient launch, and (sc1) of the backward phase of the
             // sibling blocks of this row-block
-            if (wave == part) {
-                float *h1T = isq ? d.QH1T + (size_t)net * H * B : (net == 0 ? d.PH1T : nullptr);
-                if (h1T) store_features<4, true>(keep1, 64 * wave, 16, h1T, B, row0);
-            }
-            float *h2T = isq ? d.QH2T + (size_t)net * H * B : (net == 0 ? d.PH2T : nullptr);
-            slice_epilogue<1, true>(acc, bv1, wave, XS, h2T, n0, B, row0);
+            // (the policy chain's copies are stored behind its head publish below: the head is the first link of the
+            //  step's critical path, and these 20 KB would sit in the drain in front of the signal)
+            if (isq && wave == part) store_features<4, true>(keep1, 64 * wave, 16, d.QH1T + (size_t)net * H * B, B, row0);
+            slice_epilogue<1, true>(acc, bv1, wave, XS, isq ? d.QH2T + (size_t)net * H * B : nullptr, n0, B, row0);
         }
         lds_barrier();
         if (!isq) {     // partial head pre-activations over these 64 columns
@@ -209,6 +217,9 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             gemm_ring(rh, XS, SW, 1, acc, wave);
             splitk_reduce<NTH, true>(acc, nullptr, red, d.headpart + ((size_t)(net * NB + rb) * SP + part) * (RB * 32), 32);
         } else {        // partial Q_i(s, a) over these 64 columns
+            // (early look at the head counter of phase B: the policy chains publish ~1 us before this chain gets here, so the
+            //  wait below usually finds this answer waiting and costs no round trip)
+            if (threadIdx.x == 0) peek = __hip_atomic_load(cnt_head + (size_t)rb * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float s = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, SW)] * w3[u];
@@ -221,6 +232,13 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     //  them behind the head wait below, when their stores have long left, instead of draining them here)
     if (!isq) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
     STAMP(0, 2);
+    if (!isq && net == 0) {             // pi(s)'s activations for the weight-gradient launch and the policy backward (ordered by tq)
+        if (wave == part) store_features<4, true>(keep1, 64 * wave, 16, d.PH1T, B, row0);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = XS[lds_off(4 * g + i, 16 * wave + c, SW)];
+        st4_sc1(d.PH2T + frag_off(n0 + c, row0 + 4 * g, B), v);
+    }
 
     // =========================================================================================================
     // phase B: requests that do not depend on the hand-off first, then the wait
@@ -235,17 +253,15 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const float *epp = side ? d.eps2 : d.eps1;
     const int am = (a < A) ? a : 0;
     const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
-    float eps = 0.f;
-    if (a < A)
-        eps = epp ? epp[grow * A + am]
-                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
+    if (a < A && epp) eps = epp[grow * A + am];            // (caller-supplied noise; the device stream's draw was made at entry)
     // (a handful of small loads that do not depend on the hand-off either: the s' rows of the target net / the batch action)
     RowRegs<8> rows2;
     float abat = 0.f;
     if (isq) abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
     else rows2.issue(d.KQ, S + SL.off_nobs + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
-    if (threadIdx.x == 0) s_ok = handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
-    if (isq) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // phase A's stores (and two small loads): long done
+    if (threadIdx.x == 0)
+        s_ok = (isq && (int)(peek - 4u * seq) >= 0) ? 1 : handoff_wait(cnt_head + (size_t)(side * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag);
+    if (isq) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // phase A's stores (and two small loads): ~1 us old
     lds_barrier();
     if (!s_ok) return;
     if (isq && threadIdx.x == 0) __hip_atomic_fetch_add(cnt_qa + (size_t)rb * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -499,8 +515,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
         SB();
         for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
-        handoff_wait_multi(2, cnt_head + (size_t)rb * CNT_STRIDE, 4u * seq, cnt_lp, (unsigned)NB * seq, cnt_lp, (unsigned)NB * seq,
-                           d.abort_flag, &s_ok);               // pi(s) blocks' phase A (long done), the log-pi sums
+        handoff_wait_multi(2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp, (unsigned)NB * seq, cnt_lp, (unsigned)NB * seq,
+                           d.abort_flag, &s_ok);               // the policy chains' phases A + B (pi(s)'s activations), the log-pi sums
         lds_barrier();
         if (!s_ok) return;
         f32x4 h2v[4];

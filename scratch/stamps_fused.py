@@ -18,8 +18,9 @@ blocks = [b for b in range(512) if w[b, 0] > 0]
 t0 = min(w[b, 0] for b in blocks)
 names = ["start", "A done", "A published", "B wait over", "head done", "q partial out", "B done", "B published", "C wait over", "end",
          "D wait over", "D done"]
-for sel, name in ((lambda b: (b & 7) < 4, "critic chain"), (lambda b: (b & 7) in (4, 5), "policy chain s"),
-                  (lambda b: (b & 7) in (6, 7), "policy chain s'")):
+XOR = 4     # SAC_XR_XOR of the build: role index xr = (b % 8) ^ XOR  (0-3 critic chain, 4-5 policy on s, 6-7 policy on s')
+for sel, name in ((lambda b: ((b & 7) ^ XOR) < 4, "critic chain"), (lambda b: ((b & 7) ^ XOR) in (4, 5), "policy chain s"),
+                  (lambda b: ((b & 7) ^ XOR) in (6, 7), "policy chain s'")):
     bl = [b for b in blocks if sel(b)]
     ww = w[bl]
     ns = 12 if ww[:, 11].max() > 0 else 10
@@ -33,7 +34,7 @@ b4 = [b for b in range(512) if w4[b, 0] > 0]
 if b4:
     t4 = min(w4[b, 0] for b in b4)
     print("k_dw_adam: start spread", (max(w4[b, 0] for b in b4) - t4) / 100.0, "end max", (w4[b4][:, 2].max() - t4) / 100.0,
-          "| gap abc end -> dw start", (t4 - max(w[b, 9] for b in blocks if (b & 7) < 6)) / 100.0)
+          "| gap abc end -> dw start", (t4 - max(w[b, 9] for b in blocks)) / 100.0)
 w3 = st[3]
 b3 = [b for b in range(512) if w3[b, 0] > 0]
 if b3 and b4:
@@ -47,7 +48,7 @@ if bl and bp:
     print("this step: k_abc first start -> k_dw_adam first start %.2f us; k_dw_adam tiles end %.2f us after its first start"
           % ((min(wl[b, 0] for b in bl) - t0) / 100.0, (wl[bl][:, 2].max() - min(wl[b, 0] for b in bl)) / 100.0))
 w1 = st[1]
-b1 = [b for b in blocks if (b & 7) < 4 and w1[b, 0] > 0]
+b1 = [b for b in blocks if ((b & 7) ^ XOR) < 4 and w1[b, 0] > 0]
 if b1:
     print("critic phase C (median, after C wait over): dq ready %.2f  dL/dh2 in LDS %.2f  slice GEMM done %.2f  end %.2f"
           % (tuple(np.median(w1[b1][:, i] - w[b1][:, 8]) / 100.0 for i in range(3)) + (np.median(w[b1][:, 9] - w[b1][:, 8]) / 100.0,)))
@@ -61,6 +62,6 @@ for st_i, nm in ((1, "A done"), (6, "B done"), (9, "end")):
     for key, f in (("b%8", lambda b: b & 7), ("part", lambda b: (2 * (b >> 3) + (b & 1)) & 3), ("rb", lambda b: (2 * (b >> 3) + (b & 1)) >> 2)):
         g = collections.defaultdict(list)
         for b in blocks:
-            if (b & 7) < 4:
+            if ((b & 7) ^ XOR) < 4:
                 g[f(b)].append((w[b, st_i] - t0) / 100.0)
         print(f"critic chain {nm:7s} by {key:5s}:", " ".join(f"{k}:{np.median(v):.2f}" for k, v in sorted(g.items())))
