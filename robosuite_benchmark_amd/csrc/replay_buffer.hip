@@ -493,7 +493,7 @@ static int buffer_build(sac_buffer *b, int64_t capacity, int obs_dim, int act_di
     SAC_HIP(hipMalloc(&b->rew, sizeof(float) * capacity));
     SAC_HIP(hipMalloc(&b->term, sizeof(float) * capacity));
     SAC_HIP(hipMalloc(&b->d_rng, sizeof(MtState)));
-    for (auto &e : b->ev) SAC_HIP(hipEventCreate(&e));
+    for (auto &e : b->ev) { SAC_HIP(hipEventCreate(&e)); SAC_HIP(hipEventRecord(e, b->stream)); }     // (first record = signal set-up)
     return sac_rng_seed(b, 5489u);
 }
 
