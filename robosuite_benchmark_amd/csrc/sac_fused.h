@@ -103,7 +103,7 @@ __device__ __forceinline__ AlphaStep alpha_step_v(const Ctl *ctl, const float *p
     return r;
 }
 
-template <int NTH>
+template <int NTH, bool WIDE>
 __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     constexpr int SP = 4, SW = 64;
@@ -153,18 +153,34 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const Layer L0 = isq ? d.LQ[0] : d.LP[0], L1 = isq ? d.LQ[1] : d.LP[1], L2 = isq ? d.LQ[2] : d.LP[2];
         const int K0 = isq ? d.KQ : d.KP;
         const float *obs = S + ((!isq && net) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
-        RowRegs<8> rows;
+        RowRegs<WIDE ? 32 : 8> rows;
         rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, isq ? A : 0, A, d.KP);
-        WRing<4, RD0> r0;
+        WRing<4, WIDE ? RD : RD0> r0;
         r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
         constexpr int PRE0 = 2;
-        r0.fill_part(K0 >> 4, 0, PRE0);
+        if constexpr (WIDE) r0.fill(K0 >> 4);                 // (wide first layers: a refilling ring, as in k_fwd_a)
+        else r0.fill_part(K0 >> 4, 0, PRE0);
         float bv0[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
         SB();
         WRing<1, 8> r1;
         r1.init(P + L1.offW, H, n0, 16);
+        if constexpr (WIDE) r1.fill(H >> 4);
+        WRing<NTH, 1> rh;                                     // policy chain: head rows x this wave's 16 columns
+#define ABC_LATE_REQUESTS()                                                                             \
+        do {                                                                                            \
+            bv1[0] = P[L1.offB + n0 + c];                                                               \
+            _Pragma("unroll") for (int u = 0; u < 4; ++u) w3[u] = 0.f;                                  \
+            if (!isq) {                                                                                 \
+                rh.init(P + L2.offW, H, 0, 16, 4 * part + wave);                                        \
+                rh.fill(1);                                                                             \
+            } else {                                                                                    \
+                _Pragma("unroll") for (int u = 0; u < 4; ++u) w3[u] = P[L2.offW + frag_off(0, SW * part + a + 16 * u, H)]; \
+            }                                                                                           \
+            SB();                                                                                       \
+        } while (0)
+        if constexpr (WIDE) ABC_LATE_REQUESTS();
         // The N(0,1) draw of phase B's rsample depends on nothing but (seed, step, row, action): it is computed HERE, behind
         // the block's first requests, in the ~1.3 us it waits for their data anyway (in phase B it would sit on the
         // critical path: the head partials are usually there before this chain is).
@@ -173,12 +189,12 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             const float *epp0 = side0 ? d.eps2 : d.eps1;
             if (a < A && !epp0) eps = philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side0 ? 1u : 0u);
         }
-
         rows.commit(X0, KLQ, K0, O, d.KP, isq ? A : 0);
         lds_barrier();
         {   // first layer, all 256 features (recomputed by the 4 blocks of this row-block)
             f32x4 acc[4] = {};
-            gemm_straight_pf(r0, X0, KLQ, K0 >> 4, acc, r1, H >> 4, PRE0);
+            if constexpr (WIDE) gemm_ring(r0, X0, KLQ, K0 >> 4, acc);
+            else gemm_straight_pf(r0, X0, KLQ, K0 >> 4, acc, r1, H >> 4, PRE0);
             // the critic chain keeps the PRE-activation z = W1 [s, a] + b in registers: the layer is linear in the action,
             // so phase B gets Q_i(s, a_new)'s first layer as z + W1[:, action chunk] (a_new - a)
 #pragma unroll
@@ -188,18 +204,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             hidden_epilogue<4>(acc, 64 * wave, 16, bv0, X1, H, keep1);
         }
         lds_barrier();
-        bv1[0] = P[L1.offB + n0 + c];
-        WRing<NTH, 1> rh;                                     // policy chain: head rows x this wave's 16 columns
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w3[u] = 0.f;
-        if (!isq) {
-            rh.init(P + L2.offW, H, 0, 16, 4 * part + wave);
-            rh.fill(1);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w3[u] = P[L2.offW + frag_off(0, SW * part + a + 16 * u, H)];
-        }
-        SB();
+        if constexpr (!WIDE) ABC_LATE_REQUESTS();
+#undef ABC_LATE_REQUESTS
         {   // this block's 64 columns of the 256x256 layer; the critic chain also leaves the slice in LDS, transposed
             f32x4 acc[1] = {};
             if (isq) gemm_ring<true>(r1, X1, H, H >> 4, acc, 0, WL + 16 * wave);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const int p4 = isq ? net : 2 + net;                       // Q1, Q2 on (s, a_new) | T1, T2 on (s', a')
     const int side = isq ? 0 : 1, pass = 2 + p4;
     const float *PQ = d.P[1 + p4];
-    const int KS0 = d.KQ >> 4, lo0 = isq ? KS0 - 1 : 0;       // critic chain: only the action chunk of the first layer
+    const int KS0 = d.KQ >> 4, lo0 = (isq && !WIDE) ? KS0 - 1 : 0;   // critic chain: only the action chunk of the first layer
     // The N(0,1) draw of rsample does not depend on the hand-off: it is computed in front of the wait.  Then the wait
     // itself, with NOTHING of this block in flight (a poll queued behind a CU's own weight requests returns only when
     // they have: +1-2 us), and only then the weight requests -- they land under the head math.
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
     if (a < A && epp) eps = epp[grow * A + am];            // (caller-supplied noise; the device stream's draw was made at entry)
     // (a handful of small loads that do not depend on the hand-off either: the s' rows of the target net / the batch action)
-    RowRegs<8> rows2;
+    RowRegs<WIDE ? 32 : 8> rows2;
     float abat = 0.f;
     if (isq) abat = S[SL.off_act + (size_t)grow * A + ((a < A) ? a : 0)];
     else rows2.issue(d.KQ, S + SL.off_nobs + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
@@ -283,9 +289,12 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
 #pragma unroll
         for (int t = 0; t < 4; ++t) bv0b[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
     }
-    WRing<4, RD0> q0;
-    q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
-    q0.fill_part(KS0, 0, RD0, lo0);
+    // (wide first layers: a refilling ring -- for the critic chain it starts AT the action chunk and walks one chunk)
+    const int so0 = (WIDE && isq) ? KS0 - 1 : 0, ks0 = (WIDE && isq) ? 1 : KS0;
+    WRing<4, WIDE ? RD : RD0> q0;
+    q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, so0);
+    if constexpr (WIDE) q0.fill(ks0);
+    else q0.fill_part(KS0, 0, RD0, lo0);
     WRing<1, 8> q1;
     q1.init(PQ + d.LQ[1].offW, H, n0, 16);
     q1.fill(H >> 4);
@@ -322,7 +331,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     }
     STAMP(0, 4);
     // ---- Q / target-Q net on cat(obs, action) ----
-    gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
+    if constexpr (WIDE) gemm_ring(q0, X0, KLQ, ks0, acc0, so0);
+    else gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
     hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
     WRing<1, 4> ra;                                          // W1^T action rows: this wave's 64 first-hidden features
     if (isq) {

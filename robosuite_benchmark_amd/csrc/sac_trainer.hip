@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_fwd_a(Dev d, const float *__restrict__ 
         if (wave / NTW == part) {
             float *h1T = is_pi ? (sq == 0 ? d.PH1T : nullptr) : d.QH1T + (size_t)sq * H * B;
             if (h1T) store_features<4>(keep1, 64 * wave, 16, h1T, B, row0);
-            if (MODE == M_SAC && !is_pi && !WIDE) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
+            if (MODE == M_SAC && !is_pi) store_features<4>(zkeep, 64 * wave, 16, d.QU + (size_t)sq * H * B, B, row0);
         }
         float *h2T = is_pi ? (sq == 0 ? d.PH2T : nullptr) : d.QH2T + (size_t)sq * H * B;
         slice_epilogue<NTW>(acc, bv1, wave, XS, h2T, n0, B, row0);
@@ -766,18 +766,20 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
         if constexpr (MODE == M_SAC) hbr = PH[d.LP[2].offB + A + am];
         if (MODE != M_TD3_ACTOR && epp) epsin = epp[grow * A + am];
     }
-    // Q1/Q2(s, a_new) blocks (narrow first layers): launch A left the first-layer pre-activations z of Q_i(s, a) in
-    // QU and the layer is linear in the action, so z + W1[:, action chunk] (a_new - a) needs only the action chunk
-    // of the weights and of the input; target-net blocks do the whole layer.
-    const bool act_only = (MODE == M_SAC) && !WIDE && (p4 < 2);
+    // Q1/Q2(s, a_new) blocks: launch A left the first-layer pre-activations z of Q_i(s, a) in QU and the layer is linear
+    // in the action, so z + W1[:, action chunk] (a_new - a) needs only the action chunk of the weights and of the
+    // input; target-net blocks do the whole layer.  (Wide first layers: the ring starts AT the action chunk.)
+    const bool act_only = (MODE == M_SAC) && (p4 < 2);
     constexpr int D0 = WIDE ? RD : RD0, Q0 = D0 / 4;         // first-layer ring, issued in four pieces
     const int KS0 = d.KQ >> 4;
-    const int lo0 = act_only ? KS0 - 1 : 0;                  // first chunk of the first layer this block computes
+    const int lo0 = (act_only && !WIDE) ? KS0 - 1 : 0;       // narrow: first chunk of the first layer this block computes
+    const int so0 = (act_only && WIDE) ? KS0 - 1 : 0;        // wide: the ring's first chunk
+    const int ks0 = (act_only && WIDE) ? 1 : KS0;            // chunks the ring walks
     RowRegs<WIDE ? 32 : 8> rows;
     f32x4 acc0[4] = {}, keep1[4];                            // first-layer accumulators (start: 0, or launch A's z)
     if (!act_only) rows.issue(d.KQ, S + (side ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O, O, O, nullptr, 0, 0, 0);
     WRing<4, D0> r0;
-    r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16);
+    r0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, so0);
     float bv0[4];
     float abat = 0.f;                                        // the batch action a (act_only blocks)
     if (act_only) {
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     constexpr int RD1 = ring_depth(NTW), QR = RD1 / 4;
     WRing<NTW, RD1> r1;
     r1.init(PQ + d.LQ[1].offW, H, n0, 16);
-    r0.fill_part(KS0, 0, Q0, lo0);
+    r0.fill_part(ks0, 0, Q0, lo0);
     r1.fill_part(H >> 4, 0, act_only ? QR : 0);
     SB();
     STAMP(1, 9);
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     if (!act_only) rows.commit(XQ, KLQ, d.KQ, O, 0, 0, d.KP, d.KP + 16);     // the head writes the action chunk
     STAMP(1, 1);
     SB();
-    r0.fill_part(KS0, Q0, 2 * Q0, lo0);
+    r0.fill_part(ks0, Q0, 2 * Q0, lo0);
     r1.fill_part(H >> 4, QR, act_only ? 2 * QR : 0);
     SB();
     // ---- tanh-Gaussian head on this block's rows (every block of the row-block computes the same), in three
@@ -825,7 +827,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
                       : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), side ? 1u : 0u);
     }
     SB();
-    r0.fill_part(KS0, 2 * Q0, 3 * Q0, lo0);
+    r0.fill_part(ks0, 2 * Q0, 3 * Q0, lo0);
     r1.fill_part(H >> 4, 2 * QR, act_only ? 3 * QR : 0);
     SB();
     if (a < A) {
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     // the whole action chunk (0 beyond A); act_only blocks contract the difference to the batch action
     XQ[lds_off(row, d.KP + a, KLQ)] = (a < A) ? (act_only ? act - abat : act) : 0.f;
     SB();
-    r0.fill_part(KS0, 3 * Q0, D0, lo0);
+    r0.fill_part(ks0, 3 * Q0, D0, lo0);
     r1.fill_part(H >> 4, act_only ? 3 * QR : 0, act_only ? RD1 : RD1 / 2);
     SB();
     if (MODE == M_SAC && a < A) {
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     STAMP(1, 2);
     // ---- Q / target-Q net on cat(obs, action) ----
     {
-        if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, KS0, acc0);
+        if constexpr (WIDE) gemm_ring(r0, XQ, KLQ, ks0, acc0, so0);
         else gemm_straight(r0, XQ, KLQ, KS0, acc0, lo0);
         hidden_epilogue<4>(acc0, 64 * wave, 16, bv0, X1, H, keep1);
     }
@@ -1938,6 +1940,8 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     SAC_REQUIRE(cfg->hidden == H, "hidden size %d unsupported (only 256, as in every shipped variant.json)", cfg->hidden);
     SAC_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16,
                 "unsupported dims obs=%d act=%d (act_dim must be in 1..16)", cfg->obs_dim, cfg->act_dim);
+    SAC_REQUIRE(cfg->obs_dim <= 496, "obs_dim %d unsupported: the row staging of the step kernels holds cat(obs, act) rows of at "
+                "most 512 columns (obs_dim <= 496; the shipped tasks reach 379)", cfg->obs_dim);
     SAC_REQUIRE(cfg->batch > 0, "batch size %d must be positive", cfg->batch);
     SAC_REQUIRE(cfg->target_update_period > 0, "target_update_period must be positive");
     SAC_HIP(hipSetDevice(cfg->device));
@@ -2124,17 +2128,17 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     }
 #undef SAC_PICK
 #undef TD3_PICK
-    // The fused step (sac_fused.h) needs: SAC, column split 4 (at most 16 row-blocks), narrow first layers, and every
-    // one of its 16*NB workgroups resident at once (one per CU: ~106 KB of LDS each).  SAC_FUSED=0 selects the
+    // The fused step (sac_fused.h) needs: SAC, column split 4 (at most 16 row-blocks), and every one of its 16*NB
+    // workgroups resident at once (one per CU: 100-160 KB of LDS each, which also bounds obs_dim to ~1000).  SAC_FUSED=0 selects the
     // four-launch step (co-tenant processes on one GPU; ablations).
     {
         int cus = 0;
         SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
         const char *e = getenv("SAC_FUSED");
-        t->fused = !td3 && t->SP == 4 && !wide && t->NB <= 16 && 16 * t->NB <= cus && !(e && atoi(e) == 0);
-        if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
-        t->abc = (nth == 1) ? &k_abc<1> : &k_abc<2>;
         t->lds_abc = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + FUSED_RED + H * WLD);
+        t->fused = !td3 && t->SP == 4 && t->NB <= 16 && 16 * t->NB <= cus && t->lds_abc <= 160 * 1024 - 512 && !(e && atoi(e) == 0);
+        if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
+        t->abc = (nth == 1) ? (wide ? &k_abc<1, true> : &k_abc<1, false>) : (wide ? &k_abc<2, true> : &k_abc<2, false>);
         if (t->fused) {
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->abc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)t->lds_abc));

@@ -48,11 +48,13 @@ def _same(sa, sb):
     assert np.array_equal(sa["scalars"], sb["scalars"])
 
 
-# every sweep shape the fused step serves (narrow first layers, batch <= 256), odd batch sizes (padded row-blocks),
-# one and sixteen row-blocks, both head widths (2A <= 16 and > 16)
+# every sweep shape (batch <= 256), odd batch sizes (padded row-blocks), one and sixteen row-blocks, both head widths
+# (2A <= 16 and > 16), narrow and wide first layers
 @pytest.mark.parametrize("O,A,B,steps", [(42, 7, 256, 40), (42, 7, 128, 30), (46, 7, 256, 12), (55, 7, 256, 12), (73, 12, 256, 12),
                                          (86, 14, 256, 12), (89, 14, 256, 12), (64, 4, 128, 12), (50, 4, 100, 12),
-                                         (10, 3, 16, 25), (112, 16, 48, 8), (1, 1, 17, 8), (60, 7, 250, 8)])
+                                         (10, 3, 16, 25), (112, 16, 48, 8), (1, 1, 17, 8), (60, 7, 250, 8),
+                                         # wide first layers (obs_dim > 112: a refilling ring instead of a held one): Wipe
+                                         (379, 6, 256, 10), (379, 7, 128, 6), (130, 5, 64, 8), (113, 7, 48, 6), (496, 3, 32, 4)])
 def test_fused_step_equals_four_launch_step_bitwise(O, A, B, steps):
     fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9)
     assert fused.is_fused() and not plain.is_fused()
@@ -74,9 +76,17 @@ def test_fused_step_equals_four_launch_step_bitwise(O, A, B, steps):
         assert np.array_equal(fused.debug_fetch(name, n), plain.debug_fetch(name, n)), name
 
 
+def test_unsupported_shapes_are_refused_not_miscomputed():
+    from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy
+    pol = TanhGaussianPolicy([256, 256], 500, 3)
+    qs = [FlattenMlp([256, 256], 1, 503) for _ in range(4)]
+    with pytest.raises(RuntimeError, match="obs_dim 500 unsupported"):
+        SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=32)
+
+
 def test_which_shapes_take_the_fused_step():
-    for (O, A, B), want in (((42, 7, 256), True), ((42, 7, 512), False), ((379, 6, 256), False), ((112, 7, 64), True),
-                            ((113, 7, 64), False), ((42, 7, 1), True)):
+    for (O, A, B), want in (((42, 7, 256), True), ((42, 7, 512), False), ((379, 6, 256), True), ((112, 7, 64), True),
+                            ((113, 7, 64), True), ((42, 7, 1), True), ((42, 7, 272), False)):
         _, hip = make_pair(O, A, B, seed=1)
         assert hip.is_fused() is want, (O, A, B)
 
