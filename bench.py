@@ -260,13 +260,16 @@ def td3_main(args):
     print(json.dumps(out), flush=True)
 
 
-def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False):
+def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, fused=False):
     """Extra data point, never `value`: R independent runs (own buffer, nets, streams) driven from R host threads
     on ONE GPU -- the reference's real workload is 5 seeds x 29 configurations of independent jobs
     (/root/reference/launch_jobs.sh:15-24), and a single batch-256 run leaves most of the chip idle."""
     import threading
-    # co-tenant runs: the fused step needs the whole chip to itself, so the replicas take the four-launch step
-    os.environ["SAC_FUSED"] = "0"
+    # co-tenant runs: the fused step needs the whole chip to itself, so the replicas take the four-launch step -- unless
+    # `fused`: then the library serialises their fused launches, and one run's weight-gradient launch (small blocks) can
+    # share the chip with the next run's fused launch
+    if not fused:
+        os.environ["SAC_FUSED"] = "0"
     reps = [build_replica(task, O, A, B, 100_000, 100 + i, device) for i in range(n_replicas)]
     os.environ.pop("SAC_FUSED", None)
     if by_xcd:          # experiment: replica i confined to the 32 CUs of XCD i % 8 (CU-masked streams)
@@ -285,7 +288,8 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False):
     el = time.perf_counter() - t0
     return dict(replicas=n_replicas, steps_each=steps, value=round(n_replicas * steps / el, 2), unit="grad-steps/s",
                 placement="one XCD (32 CUs) per replica, CU-masked streams" if by_xcd else "every launch spans the chip",
-                note="aggregate of independent runs sharing one GPU (100000-slot buffers, four-launch step); not the headline metric")
+                step="fused (launches serialised across runs)" if fused and not by_xcd else "four launches",
+                note="aggregate of independent runs sharing one GPU (100000-slot buffers); not the headline metric")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -374,6 +378,7 @@ def main():
     ap.add_argument("--agent", type=str, default="SAC", choices=["SAC", "TD3"],
                     help="TD3: the SURVEY 8f row on the same workload shape (N=1, its own JSON line); default SAC = the headline metric")
     ap.add_argument("--xcd-replicas", action="store_true", help="with --replicas-per-gpu: confine replica i to XCD i % 8")
+    ap.add_argument("--fused-replicas", action="store_true", help="with --replicas-per-gpu: the replicas keep the fused step")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="N=1 only: also time R concurrent independent runs on the GPU (reported beside, never as, value)")
     args = ap.parse_args()
@@ -581,7 +586,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
                                   "(call returns) vs rows resident in HBM")
     if world == 1 and args.replicas_per_gpu > 1:
         out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device,
-                                                         by_xcd=args.xcd_replicas)
+                                                         by_xcd=args.xcd_replicas, fused=args.fused_replicas)
     return out
 
 
