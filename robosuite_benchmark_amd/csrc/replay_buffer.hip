@@ -513,6 +513,7 @@ int sac_buffer_destroy(sac_buffer_t *b) {
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_free) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->free4) if (e) (void)hipEventDestroy(e);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
     return 0;
@@ -708,6 +709,11 @@ static int ensure_ring(sac_buffer *b, int batch) {
         if (!b->ring_ready[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_ready[i], hipEventDisableTiming));
         if (!b->ring_free[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_free[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < 4; ++i) {
+        if (!b->free4[i]) SAC_HIP(hipEventCreateWithFlags(&b->free4[i], hipEventDisableTiming));
+        b->free4_seq[i] = -1;
+    }
+    b->free_waited_seq = b->step_seq - 1;
     return 0;
 }
 
@@ -718,7 +724,23 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     const int64_t n = b->ring_next;
     const int slot = (int)(n % sac_buffer::NRING);
     // the slot's previous batch may still be read by a step in flight on a trainer's stream
-    if (b->ring_in_use[slot]) { SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0)); b->ring_in_use[slot] = false; }
+    if (b->ring_in_use[slot]) {
+        if (b->multi_stream) {
+            SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
+        } else if (b->free_waited_seq < b->slot_seq[slot]) {
+            const int64_t m = b->slot_seq[slot] | 3;
+            const int idx = (int)((m >> 2) & 3);
+            if (b->free4_seq[idx] == m) {                   // the usual case: recorded ~12 steps ago, long fired
+                SAC_HIP(hipStreamWaitEvent(b->stream, b->free4[idx], 0));
+                b->free_waited_seq = m;
+            } else {                                        // no event at or behind that step yet: record one now
+                SAC_HIP(hipEventRecord(b->ring_free[slot], b->step_stream));
+                SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
+                b->free_waited_seq = b->step_seq - 1;
+            }
+        }
+        b->ring_in_use[slot] = false;
+    }
     int64_t *didx = b->d_ring_idx + (size_t)slot * b->ring_layout.B;
     if (launch_sample(b, batch, 1, 0, didx)) return -1;
     if (launch_gather(b, didx, b->ring_layout.B, 1, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;

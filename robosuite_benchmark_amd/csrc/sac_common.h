@@ -124,7 +124,17 @@ struct sac_buffer {
     int64_t ring_next = 0;                           // number of batches drawn so far
     int64_t ring_token[NRING];                       // batch number held by each slot (-1: none)
     hipEvent_t ring_ready[NRING] = {}, ring_free[NRING] = {};
-    bool ring_in_use[NRING] = {};                    // a step was launched on the slot (ring_free recorded)
+    bool ring_in_use[NRING] = {};                    // a step was launched on the slot and nobody has waited for it since
+    // "the trainer is done with this slot" is signalled by ONE event per four steps (two runtime calls per step was a
+    // fifth of the stepwise interface's host time): step k (launch sequence) leaves its number in the slot, every fourth
+    // step records free4[(k >> 2) & 3]; a draw that reuses a slot waits for the oldest event recorded at or behind the
+    // slot's step (the per-slot event ring_free[] is the fall-back when no such event exists)
+    hipEvent_t free4[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t free4_seq[4] = {-1, -1, -1, -1};
+    int64_t step_seq = 0, free_waited_seq = -1;
+    int64_t slot_seq[NRING] = {};
+    hipStream_t step_stream = nullptr;               // the stream the steps are launched on (one trainer per buffer; a second
+    bool multi_stream = false;                       // stream switches to one event per step)
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
 };
 

@@ -2354,8 +2354,15 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     const int rc_step = launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr);
     t->publish_diag = true;
     if (rc_step) return -1;
-    SAC_HIP(hipEventRecord(b->ring_free[slot], s));
-    b->ring_in_use[slot] = true;
+    {   // (see sac_buffer::free4: one "done with the slots so far" event per four steps)
+        if (b->step_stream && b->step_stream != s) b->multi_stream = true;
+        b->step_stream = s;
+        const int64_t k = b->step_seq++;
+        b->slot_seq[slot] = k;
+        if (b->multi_stream) SAC_HIP(hipEventRecord(b->ring_free[slot], s));
+        else if ((k & 3) == 3) { SAC_HIP(hipEventRecord(b->free4[(k >> 2) & 3], s)); b->free4_seq[(k >> 2) & 3] = k; }
+        b->ring_in_use[slot] = true;
+    }
     t->mirror_valid = false;
     if (diag) {
         SAC_HIP(hipStreamSynchronize(s));
