@@ -123,7 +123,7 @@ int sac_read_slot(sac_buffer_t *buf, int64_t slot, float *obs, float *act, float
  * ------------------------------------------------------------------------------------------ */
 typedef struct sac_config {
     int32_t obs_dim, act_dim;
-    int32_t hidden;              /* both hidden layers; 256 in every shipped variant.json */
+    int32_t hidden;              /* both hidden layers; 256 in every shipped variant.json (see policy_hidden / qf_hidden) */
     int32_t batch;               /* algorithm_kwargs.batch_size: any positive size (slots are padded to whole 16-row
                                   * blocks; pad rows carry zero weight in every mean of the step) */
     float discount;              /* trainer_kwargs.discount */
@@ -136,6 +136,11 @@ typedef struct sac_config {
     uint64_t noise_seed;         /* device counter-based N(0,1) stream for rsample */
     int32_t device;
     int32_t reserved;
+    /* policy_kwargs / qf_kwargs hidden_sizes (/root/reference/util/arguments.py:98,104): two layers of at most 256 units
+     * each, per network family; 0 = `hidden`.  Narrower layers run EXACTLY on the 256-wide kernels: the missing units are
+     * zero rows / columns whose gradients, Adam updates and Polyak averages are identically zero. */
+    int32_t policy_hidden[2];
+    int32_t qf_hidden[2];
 } sac_config_t;
 
 enum { SAC_NET_POLICY = 0, SAC_NET_QF1 = 1, SAC_NET_QF2 = 2, SAC_NET_TARGET_QF1 = 3, SAC_NET_TARGET_QF2 = 4,
@@ -164,6 +169,8 @@ typedef struct td3_config {
     uint64_t noise_seed;
     int32_t device;
     int32_t reserved;
+    int32_t policy_hidden[2];                /* as in sac_config_t */
+    int32_t qf_hidden[2];
 } td3_config_t;
 int td3_trainer_create(sac_trainer_t **out, const td3_config_t *cfg);
 

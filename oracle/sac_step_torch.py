@@ -58,12 +58,13 @@ def init_mlp_params(rs: np.random.RandomState, in_dim: int, hidden, heads, init_
     return params
 
 
-def init_sac_params(obs_dim: int, act_dim: int, hidden=(256, 256), seed: int = 0):
-    """Five independently initialised nets, as rlkit_utils.py:64-97 builds them."""
+def init_sac_params(obs_dim: int, act_dim: int, hidden=(256, 256), seed: int = 0, hidden_q=None):
+    """Five independently initialised nets, as rlkit_utils.py:64-97 builds them (`hidden`: policy_kwargs hidden_sizes,
+    `hidden_q`: qf_kwargs hidden_sizes, default the same)."""
     rs = np.random.RandomState(seed)
     nets = OrderedDict()
     for name in ("qf1", "qf2", "target_qf1", "target_qf2"):
-        nets[name] = init_mlp_params(rs, obs_dim + act_dim, hidden, [1], 3e-3)
+        nets[name] = init_mlp_params(rs, obs_dim + act_dim, hidden_q or hidden, [1], 3e-3)
     nets["policy"] = init_mlp_params(rs, obs_dim, hidden, [act_dim, act_dim], 1e-3)
     return nets
 

@@ -34,6 +34,7 @@ class SacConfig(C.Structure):
         ("soft_target_tau", C.c_float), ("target_update_period", C.c_int32),
         ("use_automatic_entropy_tuning", C.c_int32), ("target_entropy", C.c_float),
         ("noise_seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("policy_hidden", C.c_int32 * 2), ("qf_hidden", C.c_int32 * 2),
     ]
 
 
@@ -44,6 +45,7 @@ class Td3Config(C.Structure):
         ("qf_learning_rate", C.c_float), ("tau", C.c_float), ("target_policy_noise", C.c_float),
         ("target_policy_noise_clip", C.c_float), ("policy_and_target_update_period", C.c_int32),
         ("noise_seed", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("policy_hidden", C.c_int32 * 2), ("qf_hidden", C.c_int32 * 2),
     ]
 
 

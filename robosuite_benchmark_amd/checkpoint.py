@@ -156,10 +156,10 @@ def load_checkpoint(dirname, trainer, replay_buffer=None):
 
 
 # ---- the reference's own checkpoint files ----------------------------------------------------------------
-def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256), agent="SAC"):
+def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256), agent="SAC", hidden_q=None):
     """(name, shape) of every parameter in rlkit's registration order (Mlp: fc0.., last_fc; the SAC policy adds
     last_fc_log_std, the TD3 TanhMlpPolicy does not) -- the order torch.save numbers the storages in."""
-    def mlp(inp, outs):
+    def mlp(inp, outs, hidden=hidden):
         names, k = [], inp
         for i, h in enumerate(hidden):
             names += [(f"fc{i}.weight", (h, k)), (f"fc{i}.bias", (h,))]
@@ -168,9 +168,10 @@ def rlkit_layer_shapes(obs_dim, action_dim, hidden=(256, 256), agent="SAC"):
             names += [(f"{head}.weight", (n, k)), (f"{head}.bias", (n,))]
         return names
     heads = [("last_fc", action_dim)] + ([("last_fc_log_std", action_dim)] if agent == "SAC" else [])
+    hq = tuple(hidden_q) if hidden_q else tuple(hidden)
     return OrderedDict(policy=mlp(obs_dim, heads),
-                       qf1=mlp(obs_dim + action_dim, [("last_fc", 1)]),
-                       qf2=mlp(obs_dim + action_dim, [("last_fc", 1)]))
+                       qf1=mlp(obs_dim + action_dim, [("last_fc", 1)], hq),
+                       qf2=mlp(obs_dim + action_dim, [("last_fc", 1)], hq))
 
 
 def read_rlkit_zip_params(path, obs_dim, action_dim, hidden=(256, 256)):
@@ -199,11 +200,13 @@ def export_torch_state_dicts(path, source, obs_dim=None, action_dim=None):
     """torch.save({net: OrderedDict(rlkit parameter name -> tensor)}) for the networks of `source`: a SACTrainer,
     or a dict {net: flat nn.Linear vector} together with obs_dim / action_dim."""
     import torch                      # only the exporter needs torch; the library itself does not
+    hidden, hidden_q = (256, 256), None
     if isinstance(source, dict):
         st = source
     else:
         st, obs_dim, action_dim = source.state_dict()["params"], source.obs_dim, source.act_dim
-    shapes = rlkit_layer_shapes(obs_dim, action_dim, agent="TD3" if "target_policy" in st else "SAC")
+        hidden, hidden_q = tuple(source.policy.hidden_sizes), tuple(source.qf1.hidden_sizes)
+    shapes = rlkit_layer_shapes(obs_dim, action_dim, hidden, agent="TD3" if "target_policy" in st else "SAC", hidden_q=hidden_q)
     shapes["target_qf1"], shapes["target_qf2"], shapes["target_policy"] = shapes["qf1"], shapes["qf2"], shapes["policy"]
     out = OrderedDict()
     for net in NETS + ("target_policy",):

@@ -1650,6 +1650,7 @@ struct sac_trainer {
     hipStream_t stream = nullptr;
     int B = 0, Bt = 0, O = 0, A = 0, KP = 0, KQ = 0, NH = 0, NB = 0, SP = 4;   // B: batch padded to row-blocks, Bt: true batch
     Net net[6];                                       // 5: TD3 target policy
+    int HP[2] = {256, 256}, HQ[2] = {256, 256};       // logical hidden sizes (<= 256: zero-padded to the kernels' 256)
     int algo = 0;                                     // 0 SAC, 1 TD3
     int td3_period = 2;                               // policy_and_target_update_period
     long long adam_t_pi = 0;                          // TD3: optimizer steps of the policy (delayed)
@@ -1739,10 +1740,11 @@ FlatMap flat_map(const sac_trainer *t, int netid) {
     FlatMap f{};
     if (netid == SAC_NET_POLICY || netid == 5) {
         f.nl = t->algo == 1 ? 3 : 4;                        // TD3: TanhMlpPolicy (one head); SAC: mean + log-std heads
-        f.N[0] = H; f.K[0] = t->O; f.N[1] = H; f.K[1] = H; f.N[2] = t->A; f.K[2] = H; f.N[3] = t->A; f.K[3] = H;
+        f.N[0] = t->HP[0]; f.K[0] = t->O; f.N[1] = t->HP[1]; f.K[1] = t->HP[0];
+        f.N[2] = t->A; f.K[2] = t->HP[1]; f.N[3] = t->A; f.K[3] = t->HP[1];
     } else {
         f.nl = 3;
-        f.N[0] = H; f.K[0] = t->O + t->A; f.N[1] = H; f.K[1] = H; f.N[2] = 1; f.K[2] = H;
+        f.N[0] = t->HQ[0]; f.K[0] = t->O + t->A; f.N[1] = t->HQ[1]; f.K[1] = t->HQ[0]; f.N[2] = 1; f.K[2] = t->HQ[1];
     }
     return f;
 }
@@ -1925,6 +1927,7 @@ int td3_trainer_create(sac_trainer_t **out, const td3_config_t *c) {
     SAC_REQUIRE(c->target_policy_noise >= 0.f && c->target_policy_noise_clip >= 0.f, "negative target policy noise");
     sac_config_t s{};
     s.obs_dim = c->obs_dim; s.act_dim = c->act_dim; s.hidden = c->hidden; s.batch = c->batch;
+    for (int i = 0; i < 2; ++i) { s.policy_hidden[i] = c->policy_hidden[i]; s.qf_hidden[i] = c->qf_hidden[i]; }
     s.discount = c->discount; s.reward_scale = c->reward_scale;
     s.policy_lr = c->policy_learning_rate; s.qf_lr = c->qf_learning_rate;
     s.soft_target_tau = c->tau; s.target_update_period = 1; s.use_automatic_entropy_tuning = 0;
@@ -1937,7 +1940,12 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
 static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td3_config_t *td3) {
     *out = nullptr;
     SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
-    SAC_REQUIRE(cfg->hidden == H, "hidden size %d unsupported (only 256, as in every shipped variant.json)", cfg->hidden);
+    for (int i = 0; i < 2; ++i) {
+        const int hp = cfg->policy_hidden[i] ? cfg->policy_hidden[i] : cfg->hidden, hq = cfg->qf_hidden[i] ? cfg->qf_hidden[i] : cfg->hidden;
+        SAC_REQUIRE(hp >= 1 && hp <= H && hq >= 1 && hq <= H,
+                    "hidden sizes policy %d / qf %d unsupported: two hidden layers of 1..256 units each (wider or deeper "
+                    "networks do not fit the kernels' 256-wide layers)", hp, hq);
+    }
     SAC_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16,
                 "unsupported dims obs=%d act=%d (act_dim must be in 1..16)", cfg->obs_dim, cfg->act_dim);
     SAC_REQUIRE(cfg->obs_dim <= 496, "obs_dim %d unsupported: the row staging of the step kernels holds cat(obs, act) rows of at "
@@ -1958,6 +1966,10 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     t->cfg = *cfg; t->device = cfg->device;
     t->Bt = cfg->batch; t->B = round_up(cfg->batch, RB); t->O = cfg->obs_dim; t->A = cfg->act_dim;
     t->algo = td3 ? 1 : 0;
+    for (int i = 0; i < 2; ++i) {
+        t->HP[i] = cfg->policy_hidden[i] ? cfg->policy_hidden[i] : cfg->hidden;
+        t->HQ[i] = cfg->qf_hidden[i] ? cfg->qf_hidden[i] : cfg->hidden;
+    }
     if (td3) t->td3_period = td3->policy_and_target_update_period;
     t->KP = round_up(t->O, 16); t->KQ = t->KP + 16; t->NH = round_up((td3 ? 1 : 2) * t->A, 16);
     t->NB = t->B / 16;
@@ -2634,28 +2646,28 @@ int sac_policy_act(sac_trainer_t *t, const float *obs, int deterministic, const 
     SAC_REQUIRE(deterministic || eps || t->algo == 1, "stochastic acting needs the N(0,1) draw (eps)");
     if (t->algo == 1) deterministic = 1;        // TanhMlpPolicy: tanh(last_fc); exploration noise is the caller's strategy
     if (!t->mirror_valid && sac_policy_mirror(t)) return -1;
-    const int O = t->O, A = t->A;
+    const int O = t->O, A = t->A, H1 = t->HP[0], H2 = t->HP[1];
     const float *p = t->h_policy.data();
-    const float *W0 = p, *b0 = W0 + (size_t)H * O, *W1 = b0 + H, *b1 = W1 + (size_t)H * H;
-    const float *Wm = b1 + H, *bm = Wm + (size_t)A * H, *Ws = bm + A, *bs = Ws + (size_t)A * H;
+    const float *W0 = p, *b0 = W0 + (size_t)H1 * O, *W1 = b0 + H1, *b1 = W1 + (size_t)H2 * H1;
+    const float *Wm = b1 + H2, *bm = Wm + (size_t)A * H2, *Ws = bm + A, *bs = Ws + (size_t)A * H2;
     float h1[H], h2[H];
-    for (int n = 0; n < H; ++n) {
+    for (int n = 0; n < H1; ++n) {
         float s = b0[n];
         for (int k = 0; k < O; ++k) s += W0[(size_t)n * O + k] * obs[k];
         h1[n] = s > 0.f ? s : 0.f;
     }
-    for (int n = 0; n < H; ++n) {
+    for (int n = 0; n < H2; ++n) {
         float s = b1[n];
-        for (int k = 0; k < H; ++k) s += W1[(size_t)n * H + k] * h1[k];
+        for (int k = 0; k < H1; ++k) s += W1[(size_t)n * H1 + k] * h1[k];
         h2[n] = s > 0.f ? s : 0.f;
     }
     for (int a = 0; a < A; ++a) {
         float m = bm[a], ls = 0.f;
-        for (int k = 0; k < H; ++k) m += Wm[(size_t)a * H + k] * h2[k];
+        for (int k = 0; k < H2; ++k) m += Wm[(size_t)a * H2 + k] * h2[k];
         if (deterministic) act[a] = tanhf(m);
         else {
             ls = bs[a];
-            for (int k = 0; k < H; ++k) ls += Ws[(size_t)a * H + k] * h2[k];
+            for (int k = 0; k < H2; ++k) ls += Ws[(size_t)a * H2 + k] * h2[k];
             ls = fminf(fmaxf(ls, LOG_SIG_MIN), LOG_SIG_MAX);
             act[a] = tanhf(m + expf(ls) * eps[a]);
         }

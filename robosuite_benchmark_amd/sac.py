@@ -48,15 +48,24 @@ class SACTrainer:
     def _new_handle(self, batch):
         cfg = SacConfig(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale, self.policy_lr,
                         self.qf_lr, self.soft_target_tau, self.target_update_period,
-                        int(self.use_automatic_entropy_tuning), self.target_entropy, self.noise_seed, self.device, 0)
+                        int(self.use_automatic_entropy_tuning), self.target_entropy, self.noise_seed, self.device, 0,
+                        (C.c_int32 * 2)(*self._hidden("policy")), (C.c_int32 * 2)(*self._hidden("qf1")))
         h = C.c_void_p()
         _lib.check(self._lib.sac_trainer_create(C.byref(h), C.byref(cfg)), "sac_trainer_create")
         return h
 
+    def _hidden(self, net):
+        """variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'] of a network family: two layers of at most 256 units (the
+        kernels' 256-wide layers carry narrower ones exactly, as zero rows / columns)."""
+        hs = [int(h) for h in getattr(self, net).hidden_sizes]
+        if len(hs) != 2 or not all(1 <= h <= 256 for h in hs):
+            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements two hidden layers of at most 256 "
+                               "units each (every shipped variant.json uses [256, 256])")
+        return hs
+
     def _create(self, batch):
-        hs = self.policy.hidden_sizes
-        if list(hs) != [256, 256] or list(self.qf1.hidden_sizes) != [256, 256]:
-            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements the benchmark's [256, 256]")
+        if not all(self._hidden(n) == self._hidden("qf1") for n in ("qf2", "target_qf1", "target_qf2")):
+            raise RuntimeError("the four Q networks must share their hidden_sizes (rlkit_utils.py:64-83 builds them so)")
         h = self._new_handle(batch)
         state = self._export_state() if self._h else None
         self._destroy()

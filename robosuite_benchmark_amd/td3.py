@@ -38,7 +38,7 @@ class TD3Trainer(SACTrainer):
         cfg = Td3Config(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale,
                         self.policy_learning_rate, self.qf_learning_rate, self.tau, self.target_policy_noise,
                         self.target_policy_noise_clip, self.policy_and_target_update_period, self.noise_seed,
-                        self.device, 0)
+                        self.device, 0, (C.c_int32 * 2)(*self._hidden("policy")), (C.c_int32 * 2)(*self._hidden("qf1")))
         h = C.c_void_p()
         _lib.check(self._lib.td3_trainer_create(C.byref(h), C.byref(cfg)), "td3_trainer_create")
         return h

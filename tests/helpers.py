@@ -30,11 +30,13 @@ def make_pair(O, A, B, seed=3, device=0, **kw):
     kw.setdefault("qf_lr", 5e-4)
     kw.setdefault("soft_target_tau", 0.005)
     kw.setdefault("target_update_period", 5)
-    nets = init_sac_params(O, A, seed=seed)
+    hidden, hidden_q = tuple(kw.pop("hidden", (256, 256))), kw.pop("hidden_q", None)
+    hidden_q = tuple(hidden_q) if hidden_q else hidden
+    nets = init_sac_params(O, A, hidden=hidden, seed=seed, hidden_q=hidden_q)
     noise_seed = kw.pop("noise_seed", 0)
     oracle = RlkitEquivalentSAC(nets, A, **kw)
-    pol = TanhGaussianPolicy([256, 256], O, A)
-    qs = [FlattenMlp([256, 256], 1, O + A) for _ in range(4)]
+    pol = TanhGaussianPolicy(list(hidden), O, A)
+    qs = [FlattenMlp(list(hidden_q), 1, O + A) for _ in range(4)]
     pol.load_flat(flat_of(nets["policy"]))
     for q, name in zip(qs, ("qf1", "qf2", "target_qf1", "target_qf2")):
         q.load_flat(flat_of(nets[name]))
