@@ -185,6 +185,15 @@ __device__ __forceinline__ T sload(const T *p) {
     return *(const __attribute__((address_space(4))) T *)(uintptr_t)p;
 }
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+// Accesses through an explicitly GLOBAL pointer (a pointer that reaches a kernel inside a table read with scalar loads,
+// DwLayer, has no address space the compiler can infer: its accesses become flat_load / flat_store).  Measured, not
+// assumed: k_dw_adam's OPERAND loads are left generic on purpose -- with global loads the same launch is 0.7 us longer
+// by rocprofv3 on the same box (7.45 against 6.7 us, scratch/ab_libs.sh), although its in-kernel stamps are not.
+__device__ __forceinline__ float ld1g(const float *p) { return *(const __attribute__((address_space(1))) float *)(uintptr_t)p; }
+// (write-through: a plain global store would sit dirty in the L2 until the end-of-kernel write-back)
+__device__ __forceinline__ void st1g(float *p, float v) {
+    __hip_atomic_store((__attribute__((address_space(1))) float *)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Kernel arguments are ~0.7 KB (11 scalar-cache lines) and hipcc loads them lazily -- an s_load right
 // before each first use, each followed by s_waitcnt lgkmcnt(0): a chain of serial misses (the scalar cache is
@@ -1349,7 +1358,7 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
 // counter hand-off: the hand-off took 6.5 us against ~3 us for the dispatch boundary plus start-up it replaced, DESIGN.md
 // section 7 -- and kept that way.)  red: 4096 floats, redb: 128 floats.
 __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, const float *__restrict__ S, const StepArg &sa,
-                                             float *red, float *redb, int vblock, unsigned aborted) {
+                                             float *red, float *redb, float *trs, int vblock, unsigned aborted) {
     const int B = d.B;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, g = lane >> 4;
@@ -1419,20 +1428,20 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
         }
         const double bc1 = sa.bc1, bc2sd = sa.bc2s;
         const bool polyak = (J.TP != nullptr) && (sa.step_now % d.period == 0);
+        // The forward copy P [n][k] (and the Polyak target, same layout) holds this wave's 16 x 16 tile as ONE contiguous
+        // 1-KB block, lane (c', g') = (n0 + c', k 4g'..4g'+3): written below with one 16-B store per lane after a
+        // transpose through LDS (four 4-B stores + four 4-B target loads per lane before: the launch ends when its stores
+        // have drained).
+        const bool tile_ok = (k0 + 16 * wave) < J.ldp;                     // (wave-uniform: the last k tile of a 48-wide layer)
+        const size_t pblk = frag_off(n0, k0 + 16 * wave, J.ldp) + 4 * lane;
         f32x4 tp4 = {0.f, 0.f, 0.f, 0.f};
-        if (polyak && own_valid) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 4 * g + i;
-                if (n < J.N) tp4[i] = J.TP[frag_off(n, k_own, J.ldp)];
-            }
-        }
+        if (polyak && tile_ok) tp4 = ld4(J.TP + pblk);
         float pb = 0.f, mbv = 0.f, vbv = 0.f, tbv = 0.f;
         const bool bias_lane = (k0 == 0) && threadIdx.x < 16 && (n0 + (int)threadIdx.x) < J.N;
         if (bias_lane) {
             const int n = n0 + threadIdx.x;
-            pb = J.bias[n]; mbv = J.mb[n]; vbv = J.vb[n];
-            if (polyak) tbv = J.Tbias[n];
+            pb = ld1g(J.bias + n); mbv = ld1g(J.mb + n); vbv = ld1g(J.vb + n);
+            if (polyak) tbv = ld1g(J.Tbias + n);
         }
 #ifdef SAC_STAMPS
         { float probe = a[0][0] + b[3][3][3]; asm volatile("" :: "v"(probe)); }
@@ -1469,36 +1478,45 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
         STAMP(4, 1);
         const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
         if (aborted) return;
-        if (own_valid) {
+        if (tile_ok) {
             f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; ++w) gsum += ld4(red + ((w * 4 + wave) * 64 + lane) * 4);
+            if (own_valid) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + 4 * g + i;
-                if (n < J.N) {
-                    float p = p4[i], m = m4[i], v = v4[i];
-                    adam_update(p, m, v, gsum[i], step_size, bc2s);
-                    p4[i] = p; m4[i] = m; v4[i] = v;
-                    const size_t o = frag_off(n, k_own, J.ldp);
-                    J.P[o] = p;
-                    if (J.G && keep_grad) J.G[o] = gsum[i];
-                    if (polyak) J.TP[o] = tp4[i] * (1.0f - d.tau) + p * d.tau;
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + 4 * g + i;
+                    if (n < J.N) {
+                        float p = p4[i], m = m4[i], v = v4[i];
+                        adam_update(p, m, v, gsum[i], step_size, bc2s);
+                        p4[i] = p; m4[i] = m; v4[i] = v;
+                        if (J.G && keep_grad) st1g(J.G + frag_off(n, k_own, J.ldp), gsum[i]);
+                    }
                 }
+                // 16-B stores of the launch's ~4 MB of new state go out write-through (sc1): plain stores would sit dirty
+                // in the L2s until the end-of-kernel write-back, in front of the next launch
+                st4_sc1(J.PT + ot, p4);
+                st4_sc1(J.MT + ot, m4);
+                st4_sc1(J.VT + ot, v4);
             }
-            // 16-B stores of the launch's ~4 MB of new state go out write-through (sc1): plain stores would sit dirty in
-            // the L2s until the end-of-kernel write-back, in front of the next launch
-            st4_sc1(J.PT + ot, p4);
-            st4_sc1(J.MT + ot, m4);
-            st4_sc1(J.VT + ot, v4);
+            // (lanes outside the layer hold zeros: p4 was never loaded or never updated, and padding is zero by invariant)
+            float *tw = trs + wave * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw[(4 * g + i) * 16 + r] = p4[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const f32x4 pf = ld4(tw + r * 16 + 4 * g);                      // this lane as (c', g') of the forward copy
+            st4_sc1(J.P + pblk, pf);
+            if (polyak) st4_sc1(J.TP + pblk, tp4 * (1.0f - d.tau) + pf * d.tau);
         }
         if (bias_lane) {
             const int n = n0 + threadIdx.x;
             const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
             adam_update(pb, mbv, vbv, gb, step_size, bc2s);
-            J.bias[n] = pb; J.mb[n] = mbv; J.vb[n] = vbv;
-            if (J.gb && keep_grad) J.gb[n] = gb;
-            if (polyak) J.Tbias[n] = tbv * (1.0f - d.tau) + pb * d.tau;
+            st1g(J.bias + n, pb); st1g(J.mb + n, mbv); st1g(J.vb + n, vbv);
+            if (J.gb && keep_grad) st1g(J.gb + n, gb);
+            if (polyak) st1g(J.Tbias + n, tbv * (1.0f - d.tau) + pb * d.tau);
         }
         STAMP(4 - 2 * (sa.loop_pos & 1), 2);
     } else if (aborted) {
@@ -1629,10 +1647,11 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
     __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
     __shared__ __attribute__((aligned(16))) float redb[4 * 16 * 2];
+    __shared__ __attribute__((aligned(16))) float trs[4 * 256];           // a wave's 16 x 16 tile on its way to the forward copy
     // fused step: the forward/backward launch gave up (a hand-off wait timed out) => this launch, the step's only
     // writer of weights, Adam state, targets and the entropy coefficient, applies NOTHING
     const unsigned aborted = T.abort ? sload(T.abort) : 0u;
-    dw_adam_body(d, T, S, sa, red, redb, (int)blockIdx.x, aborted);
+    dw_adam_body(d, T, S, sa, red, redb, trs, (int)blockIdx.x, aborted);
 }
 
 #include "sac_fused.h"
