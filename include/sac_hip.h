@@ -234,8 +234,9 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *
  * (tests/test_gpu_fused_step.py). */
 int sac_trainer_is_fused(const sac_trainer_t *t);
 
-/* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop, and
- * per-kernel-family device time accumulated over it (names via sac_kernel_name). */
+/* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop (total_ms == steps_ms: first
+ * launch to last step), and around the index draw (sample_ms) and the gather (gather_ms) of ONE of its chunks -- the
+ * second chunk when the call has one (12 batches at the default plan), else the first. */
 int sac_sync(sac_trainer_t *t);
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms);
 

@@ -22,70 +22,93 @@ void set_error(const char *fmt, ...) {
 const char *last_error() { return g_err.c_str(); }
 
 // ------------------------------------------------------------------------------------------
-// k_mt_randint: ONE wave walks the MT19937 stream in order.  The twist is wave-synchronous
-// (624 words = 10 passes of 64 lanes; element i needs old mt[i+1] and mt[i+397] or new mt[i-227],
-// both satisfied by ascending 64-wide passes).  Tempering, masking and rejection are lane-parallel;
-// accepted draws are compacted in draw order with a ballot prefix, so output j is exactly the j-th
-// accepted draw and the stream stops right after the draw that produced the last output.
+// k_mt_randint: ONE workgroup of four waves walks the MT19937 stream in order.
+//   Twist: element i of the new state needs old mt[i], old mt[i+1] and old mt[i+397] (i < 227) or NEW mt[i-227]
+//   (i >= 227), so the 624 words fall into three dependent groups -- [0,227) from the old state alone, [227,454) from the
+//   first group, [454,624) from the second (word 623 also takes the new word 0) -- each a single pass of <= 227 threads.
+//   Old and new state are two LDS arrays, so a group needs one barrier, not a read barrier and a write barrier.
+//   Draws: tempering, masking and rejection are thread-parallel over the 624 words (three per thread); accepted draws
+//   are compacted in draw order -- a ballot prefix inside a wave, the twelve (pass, wave) counts through LDS -- so output
+//   j is exactly the j-th accepted draw and the stream stops right after the draw that produced the last output.
+// Round 1 ran this on one wave (ten 64-wide passes per twist, two barriers each): 4.4 ns per index against ~1 here; the
+// draw of a loop's first chunk sits in front of its first step.
 // ------------------------------------------------------------------------------------------
 // Output j goes to out[(j / bt) * bp + j % bt]: batches of bt indices stored at a stride of bp >= bt (the row-block
 // padding of a batch whose size is not a multiple of 16; the pad entries keep a valid index and are never drawn).
-__global__ __launch_bounds__(64) void k_mt_randint(MtState *st, uint32_t rng, uint32_t mask, int64_t count,
-                                                   int64_t *__restrict__ out, int bt, int bp) {
-    __shared__ uint32_t mt[MT_N];
+__global__ __launch_bounds__(256) void k_mt_randint(MtState *st, uint32_t rng, uint32_t mask, int64_t count,
+                                                    int64_t *__restrict__ out, int bt, int bp) {
+    __shared__ uint32_t mt[2][MT_N];
+    __shared__ int s_cnt[2][12];
     __shared__ int s_newpos;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < MT_N; i += 64) mt[i] = st->mt[i];
-    int pos = st->pos;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < MT_N; i += 256) mt[0][i] = st->mt[i];
+    int pos = st->pos, cur = 0;
     __syncthreads();
+    constexpr int G = MT_N - MT_M;                 // 227
+    auto mix = [](uint32_t hi, uint32_t lo, uint32_t far) {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
     int64_t produced = 0;
-    while (produced < count) {
+    for (int it = 0;; ++it) {
         if (pos >= MT_N) {
-            for (int b = 0; b < MT_N; b += 64) {
-                const int i = b + lane;
-                uint32_t nv = 0;
-                if (i < MT_N) {
-                    const uint32_t cur = mt[i];
-                    const uint32_t nxt = mt[i + 1 == MT_N ? 0 : i + 1];
-                    const uint32_t far = mt[i + MT_M < MT_N ? i + MT_M : i + MT_M - MT_N];
-                    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
-                    nv = far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-                }
-                __syncthreads();          // all lanes have read before anyone writes
-                if (i < MT_N) mt[i] = nv;
-                __syncthreads();
-            }
+            const uint32_t *o = mt[cur];
+            uint32_t *n = mt[cur ^ 1];
+            if (tid < G) n[tid] = mix(o[tid], o[tid + 1], o[tid + MT_M]);
+            __syncthreads();
+            if (tid < G) { const int i = G + tid; n[i] = mix(o[i], o[i + 1], n[i - G]); }
+            __syncthreads();
+            if (tid < MT_N - 2 * G) { const int i = 2 * G + tid; n[i] = mix(o[i], (i == MT_N - 1) ? n[0] : o[i + 1], n[i - G]); }
+            __syncthreads();
+            cur ^= 1;
             pos = 0;
         }
-        for (int base = pos; base < MT_N; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < MT_N;
-            uint32_t y = valid ? mt[i] : 0u;
+        const uint32_t *m = mt[cur];
+        uint32_t v[3];
+        bool ok[3];
+        int before[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int i = p * 256 + tid;
+            const bool valid = i < MT_N && i >= pos;
+            uint32_t y = valid ? m[i] : 0u;
             y ^= y >> 11;
             y ^= (y << 7) & 0x9d2c5680u;
             y ^= (y << 15) & 0xefc60000u;
             y ^= y >> 18;
-            const uint32_t v = y & mask;
-            const bool ok = valid && (v <= rng);
-            const unsigned long long bal = __ballot(ok);
-            const int before = __popcll(bal & ((1ull << lane) - 1ull));
-            const int total = __popcll(bal);
-            const int64_t slot = produced + before;
-            if (ok && slot < count) out[(bt == bp) ? slot : (slot / bt) * bp + slot % bt] = (int64_t)v;
-            if (produced + total >= count) {
-                if (ok && slot == count - 1) s_newpos = i + 1;
-                __syncthreads();
-                pos = s_newpos;
-                produced = count;
-                break;
-            }
-            produced += total;
-            pos = (base + 64 < MT_N) ? base + 64 : MT_N;
+            v[p] = y & mask;
+            ok[p] = valid && (v[p] <= rng);
+            const unsigned long long bal = __ballot(ok[p]);
+            before[p] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[it & 1][p * 4 + wave] = __popcll(bal);
         }
+        __syncthreads();
+        int total = 0, base[3] = {0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int c = s_cnt[it & 1][q];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) base[p] += (q < p * 4 + wave) ? c : 0;
+            total += c;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const int64_t slot = produced + base[p] + before[p];
+            if (ok[p] && slot < count) {
+                out[(bt == bp) ? slot : (slot / bt) * bp + slot % bt] = (int64_t)v[p];
+                if (slot == count - 1) s_newpos = p * 256 + tid + 1;
+            }
+        }
+        if (produced + total >= count) {       // (uniform: every thread sums the same twelve counts)
+            __syncthreads();
+            pos = s_newpos;
+            break;
+        }
+        produced += total;
+        pos = MT_N;
     }
-    __syncthreads();
-    for (int i = lane; i < MT_N; i += 64) st->mt[i] = mt[i];
-    if (lane == 0) st->pos = pos;
+    for (int i = tid; i < MT_N; i += 256) st->mt[i] = mt[cur][i];
+    if (tid == 0) st->pos = pos;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,7 +356,8 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
 
 // `batch` indices per batch, stored at a stride of round_up(batch, 16).  dst == null: into b->d_idx + idx_offset
 // (idx_offset in elements of that padded layout; the buffer is grown as needed when idx_offset == 0).
-int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst) {
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst, hipStream_t on) {
+    hipStream_t q = on ? on : b->stream;
     const int bp = round_up(batch, RB);
     const int64_t count = (int64_t)batch * n_batches, padded = (int64_t)bp * n_batches;
     SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
@@ -345,18 +369,19 @@ int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offse
     }
     const uint32_t rng = (uint32_t)(b->size - 1);
     if (rng == 0) {     // NumPy: no draws consumed, all zeros
-        SAC_HIP(hipMemsetAsync(dst, 0, sizeof(int64_t) * padded, b->stream));
+        SAC_HIP(hipMemsetAsync(dst, 0, sizeof(int64_t) * padded, q));
         return 0;
     }
     uint32_t mask = rng;
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(64), 0, b->stream, b->d_rng, rng, mask, count, dst, batch, bp);
+    hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(256), 0, q, b->d_rng, rng, mask, count, dst, batch, bp);
     SAC_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
-                  const SlotLayout &L, int write_saT) {
+                  const SlotLayout &L, int write_saT, hipStream_t on) {
+    hipStream_t q = on ? on : b->stream;
     SAC_REQUIRE(batch > 0 && batch % RB == 0, "batch size %d must be a positive multiple of %d", batch, RB);
     const int64_t nblk = (int64_t)(batch / RB) * n_batches;
     SAC_REQUIRE(nblk < (1LL << 30), "too many rows in one gather launch");
@@ -366,7 +391,7 @@ int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batc
     const int nit = (RB * (b->Ost >> 2) + 255) / 256;            // obs chunks per thread
     SAC_REQUIRE(nit <= 8, "observation rows too wide for the gather kernel (obs_dim %d)", b->O);
 #define SAC_GATHER_LAUNCH(N)                                                                               \
-    hipLaunchKernelGGL(k_gather<N>, dim3(grid), dim3(256), lds, b->stream, b->view(), d_idx, batch, nblk, \
+    hipLaunchKernelGGL(k_gather<N>, dim3(grid), dim3(256), lds, q, b->view(), d_idx, batch, nblk, \
                        d_slots, L, write_saT)
     if (nit <= 1) SAC_GATHER_LAUNCH(1);
     else if (nit <= 2) SAC_GATHER_LAUNCH(2);

@@ -146,8 +146,9 @@ namespace sac {
 int ensure_stage(sac_buffer *b, size_t bytes);
 int ensure_idx(sac_buffer *b, int64_t n);
 int ensure_slots(sac_buffer *b, int B, int64_t n_slots);
-// launches on b->stream; indices stay in b->d_idx, slots in b->d_slots
-int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset = 0, int64_t *dst = nullptr);
+// launches on `on` (null: b->stream); indices stay in b->d_idx, slots in b->d_slots
+int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset = 0, int64_t *dst = nullptr,
+                  hipStream_t on = nullptr);
 int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
-                  const SlotLayout &L, int write_saT);
+                  const SlotLayout &L, int write_saT, hipStream_t on = nullptr);
 }  // namespace sac

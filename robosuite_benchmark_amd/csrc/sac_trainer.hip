@@ -2446,20 +2446,40 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");
     SAC_REQUIRE(b->O == t->O && b->A == t->A, "buffer dims (%d,%d) do not match trainer dims (%d,%d)", b->O, b->A,
                 t->O, t->A);
+    static const bool host_timing = getenv("SAC_HOST_TIMING") != nullptr;      // diagnostic: where the host spends the call
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto ht = [&](const char *what) {
+        if (host_timing) fprintf(stderr, "[sac_train_loop %lld] %s at %.1f us\n", (long long)n_steps, what,
+                                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
+    };
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
     if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
     if (ensure_idx(b, LOOP_RING * t->B)) return -1;
+    ht("set-up done");
     struct Live { int64_t pos, m; int ev; };
     Live live[sac_trainer::NLOOP_EV + 4];
     int n_live = 0;
+    // Chunk 0 is drawn and gathered on the TRAINER's stream, in front of its steps: a cross-stream event wait costs the
+    // waiting stream 10-17 us even when the event has long fired (a barrier packet), which was a third of a 20-step
+    // call's fixed cost.  The buffer's stream carries the later chunks; if it still has work in flight (an ingest, a
+    // random_batch nobody consumed) the trainer's stream waits for it first.
+    if (hipStreamQuery(b->stream) != hipSuccess) {
+        SAC_HIP(hipEventRecord(b->ev[3], b->stream));
+        SAC_HIP(hipStreamWaitEvent(s, b->ev[3], 0));
+    }
     SAC_HIP(hipEventRecord(t->ev[0], s));
     int64_t done = 0, pos = 0;
+    int timed = 0;
     for (int c = 0; done < n_steps; ++c) {
-        const int64_t first = done, want = loop_chunk_len(done), m = (n_steps - first < want) ? n_steps - first : want;
+        const int64_t first = done, want = loop_chunk_len(done);
+        int64_t m = (n_steps - first < want) ? n_steps - first : want;
+        // (a tail shorter than half this chunk joins it: every chunk boundary is a cross-stream wait, ~10 us of idle stream)
+        if (const int64_t rest = n_steps - first - m; rest > 0 && 2 * rest < m && m + rest <= LOOP_CH) m += rest;
         if (pos + m > LOOP_RING) pos = 0;
         const int e = c % sac_trainer::NLOOP_EV;
+        hipStream_t q = (c == 0) ? s : b->stream;
         // chunks that still own some of these slots: the trainer must be done with them
         for (int i = 0; i < n_live;) {
             if (live[i].pos < pos + m && pos < live[i].pos + live[i].m) {
@@ -2467,18 +2487,28 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
                 live[i] = live[--n_live];
             } else ++i;
         }
-        if (c == 0) SAC_HIP(hipEventRecord(b->ev[0], b->stream));
-        if (launch_sample(b, t->Bt, m, pos * t->B)) return -1;
-        if (c == 0) SAC_HIP(hipEventRecord(b->ev[1], b->stream));
-        if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1))
+        // sac_last_loop_ms reports the draw and the gather of ONE chunk: chunk 1 (on the buffer's stream, which has slack)
+        // when the call has one, else chunk 0 -- whose events then sit in front of the first step (~3 us each of host time)
+        if (c == 0) timed = (n_steps > m) ? 1 : 0;
+        if (c == timed) SAC_HIP(hipEventRecord(b->ev[0], q));
+        if (launch_sample(b, t->Bt, m, pos * t->B, nullptr, q)) return -1;
+        if (c == timed) SAC_HIP(hipEventRecord(b->ev[1], q));
+        if (c == 0) SAC_HIP(hipEventRecord(b->ev[3], q));           // (the generator's state: see below)
+        if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1, q))
             return -1;
-        if (c == 0) SAC_HIP(hipEventRecord(b->ev[2], b->stream));
-        SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
-        SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0));
+        if (c == timed) SAC_HIP(hipEventRecord(b->ev[2], q));
+        if (c == 0) ht("chunk 0 draw + gather submitted");
+        if (c > 0) {
+            SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
+            SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0));
+        }
         for (int64_t i = 0; i < m; ++i) {
             t->publish_diag = (first + i == n_steps - 1);
             if (launch_step(t, b->d_slots + (size_t)(pos + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
         }
+        // the generator's state is one in-order sequence: everything later on the buffer's stream follows chunk 0's draw
+        // (told to that stream only now, behind chunk 0's step launches: nothing of it is in front of the first step)
+        if (c == 0) SAC_HIP(hipStreamWaitEvent(b->stream, b->ev[3], 0));
         t->publish_diag = true;
         SAC_HIP(hipEventRecord(t->ev_done[e], s));
         SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV + 4, "internal: loop chunk bookkeeping overflow");
@@ -2487,6 +2517,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         done += m;
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
+    ht("all launches submitted");
     // The end of the loop is awaited by polling the last event for up to 2 ms (a user-space read of its signal) before
     // the blocking wait: the runtime's own wake-up costs 10-20 us, a seventh of a 20-step call's fixed cost.
     {
@@ -2494,6 +2525,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         while (hipEventQuery(t->ev[1]) == hipErrorNotReady && std::chrono::steady_clock::now() < spin_until) { }
     }
     SAC_HIP(hipStreamSynchronize(s));             // (the diagnostics are in mapped pinned memory: nothing to copy)
+    ht("stream idle");
     if (check_fused_abort(t)) return -3;
     if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
     if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
@@ -2502,6 +2534,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));
     t->last_ms[0] = t->last_ms[3];            // sampling + gathering of later chunks overlap the steps
     t->mirror_valid = false;
+    ht("return");
     return 0;
 }
 
