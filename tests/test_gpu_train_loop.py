@@ -85,3 +85,47 @@ def test_loop_lengths_do_not_disturb_each_other():
     sa, sb = fused.state_dict(), stepw.state_dict()
     for k in sa["params"]:
         assert np.array_equal(sa["params"][k], sb["params"][k]), k
+
+
+def test_loop_behind_work_in_flight_on_the_buffers_stream():
+    """The first chunk of a loop is drawn and gathered on the TRAINER's stream; an ingest whose copies are still in flight
+    and a device-resident random_batch nobody consumed live on the BUFFER's stream.  The loop must see the ingested rows
+    and continue the index stream behind that draw -- no explicit wait by the caller -- and a random_batch right behind
+    a one-chunk loop must continue the stream behind the loop's draw."""
+    O, A, B, n = 42, 7, 256, 60_000
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=21)
+    pairs = []
+    for waited in (False, True):
+        _, tr = make_pair(O, A, B, seed=9, noise_seed=5)
+        buf = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
+        buf.add_block(obs[:500], act[:500], rew[:500], nobs[:500], term[:500])
+        buf.seed(3)
+        out = []
+        for lo, hi, steps in ((500, 30_500, 3), (30_500, 60_000, 20), (0, 0, 2)):
+            if hi > lo:
+                buf.add_block(obs[lo:hi], act[lo:hi], rew[lo:hi], nobs[lo:hi], term[lo:hi])   # 30 000 rows: copies in flight
+            if waited:
+                buf.ingest_wait()
+                tr._lib.sac_sync(tr._h)
+            tok = buf.random_batch(B)                          # device-resident, never consumed by a step
+            if waited:
+                buf.ingest_wait()
+            first, last = tr.train_loop(buf, steps, batch_size=B)
+            _, idx = buf.random_batch(64, return_indices=True, lazy=False)
+            out.append((first, last, idx))
+            del tok
+        pairs.append((out, tr.state_dict(), buf.rng_state()))
+    (oa, sa, ra), (ob, sb, rb) = pairs
+    for (fa, la, ia), (fb, lb, ib) in zip(oa, ob):
+        assert np.array_equal(fa, fb) and np.array_equal(la, lb) and np.array_equal(ia, ib)
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    assert ra[1] == rb[1] and np.array_equal(ra[0], rb[0])
+    # and the stream is NumPy's: draws of 256 (unconsumed batch), steps x 256 (loop), 64 -- three times, sizes 30 500 / 60 000 / 60 000
+    ref = np.random.RandomState(3)
+    for (size, steps), (_, _, idx) in zip(((30_500, 3), (60_000, 20), (60_000, 2)), oa):
+        ref.randint(0, size, B)
+        for _ in range(steps):
+            ref.randint(0, size, B)
+        assert np.array_equal(idx, ref.randint(0, size, 64))
