@@ -1691,6 +1691,9 @@ struct sac_trainer {
     hipEvent_t ev_ready[NLOOP_EV] = {}, ev_done[NLOOP_EV] = {};                      // chunks of sac_train_loop in flight
     float *h_diag = nullptr, *d_diag_host = nullptr;  // mapped pinned: first[32] | last[32] (host view, device view)
     float last_ms[4] = {0, 0, 0, 0};
+    bool loop_primed = false;
+    bool timing_pending = false;                      // the last loop's event intervals have not been read yet (read lazily)
+    hipEvent_t ev_tm[3] = {nullptr, nullptr, nullptr};  // around the draw and the gather of the loop's timed chunk
     std::vector<float> h_policy;                      // host mirror for acting
     bool mirror_valid = false;
     size_t lds_bw = 0;
@@ -2015,6 +2018,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     }
     SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
+    for (auto &e : t->ev_tm) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // first[32] | last[32] of the diagnostics live in MAPPED PINNED HOST memory: the one diagnostics workgroup of a step
@@ -2208,6 +2212,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     // every event is recorded once here: the runtime sets an event's signal up at its first record, which otherwise
     // happens inside the first loop that is long enough to use it (a 20-step call behind a 5-step one: +40 us)
     for (auto &e : t->ev) SAC_HIP(hipEventRecord(e, s));
+    for (auto &e : t->ev_tm) SAC_HIP(hipEventRecord(e, s));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventRecord(e, s));
     for (auto &e : t->ev_done) SAC_HIP(hipEventRecord(e, s));
     SAC_HIP(hipStreamSynchronize(s));
@@ -2228,6 +2233,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->h_diag) (void)hipHostFree(t->h_diag);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : t->ev_tm) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_done) if (e) (void)hipEventDestroy(e);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -2483,7 +2489,15 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         SAC_HIP(hipEventRecord(b->ev[3], b->stream));
         SAC_HIP(hipStreamWaitEvent(s, b->ev[3], 0));
     }
-    SAC_HIP(hipEventRecord(t->ev[0], s));
+    if (!t->loop_primed) {
+        // first loop of this trainer: one empty hand-shake between the two streams in each direction, so that the first
+        // multi-chunk call does not pay the runtime's first-use cost of those paths (~30 us) in front of its second chunk
+        t->loop_primed = true;
+        SAC_HIP(hipEventRecord(t->ev_ready[1], b->stream));
+        SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[1], 0));
+        SAC_HIP(hipEventRecord(t->ev_done[1], s));
+        SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[1], 0));
+    }
     int64_t done = 0, pos = 0;
     int timed = 0;
     for (int c = 0; done < n_steps; ++c) {
@@ -2504,13 +2518,14 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         // sac_last_loop_ms reports the draw and the gather of ONE chunk: chunk 1 (on the buffer's stream, which has slack)
         // when the call has one, else chunk 0 -- whose events then sit in front of the first step (~3 us each of host time)
         if (c == 0) timed = (n_steps > m) ? 1 : 0;
-        if (c == timed) SAC_HIP(hipEventRecord(b->ev[0], q));
+        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[0], q));
         if (launch_sample(b, t->Bt, m, pos * t->B, nullptr, q)) return -1;
-        if (c == timed) SAC_HIP(hipEventRecord(b->ev[1], q));
+        if (c == 0) SAC_HIP(hipEventRecord(t->ev[0], s));           // start of the device span (behind the first launch: one call less in front of it)
+        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[1], q));
         if (c == 0) SAC_HIP(hipEventRecord(b->ev[3], q));           // (the generator's state: see below)
         if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1, q))
             return -1;
-        if (c == timed) SAC_HIP(hipEventRecord(b->ev[2], q));
+        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[2], q));
         if (c == 0) ht("chunk 0 draw + gather submitted");
         if (c > 0) {
             SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
@@ -2537,10 +2552,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     if (check_fused_abort(t)) return -3;
     if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
     if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
-    SAC_HIP(hipEventElapsedTime(&t->last_ms[1], b->ev[0], b->ev[1]));
-    SAC_HIP(hipEventElapsedTime(&t->last_ms[2], b->ev[1], b->ev[2]));
-    SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));
-    t->last_ms[0] = t->last_ms[3];            // sampling + gathering of later chunks overlap the steps
+    t->timing_pending = true;                 // (the event intervals are read when sac_last_loop_ms asks: ~1 us each)
     t->mirror_valid = false;
     ht("return");
     return 0;
@@ -2623,6 +2635,14 @@ int sac_trainer_is_fused(const sac_trainer_t *t) { return (t && t->fused) ? 1 : 
 
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms) {
     SAC_REQUIRE(t, "null trainer");
+    if (t->timing_pending) {
+        t->timing_pending = false;
+        SAC_HIP(hipSetDevice(t->device));
+        SAC_HIP(hipEventElapsedTime(&t->last_ms[1], t->ev_tm[0], t->ev_tm[1]));
+        SAC_HIP(hipEventElapsedTime(&t->last_ms[2], t->ev_tm[1], t->ev_tm[2]));
+        SAC_HIP(hipEventElapsedTime(&t->last_ms[3], t->ev[0], t->ev[1]));
+        t->last_ms[0] = t->last_ms[3];        // sampling + gathering of later chunks overlap the steps
+    }
     if (total_ms) *total_ms = t->last_ms[0];
     if (sample_ms) *sample_ms = t->last_ms[1];
     if (gather_ms) *gather_ms = t->last_ms[2];
