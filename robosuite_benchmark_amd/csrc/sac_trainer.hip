@@ -2481,9 +2481,9 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     struct Live { int64_t pos, m; int ev; };
     Live live[sac_trainer::NLOOP_EV + 4];
     int n_live = 0;
-    // Chunk 0 is drawn and gathered on the TRAINER's stream, in front of its steps: a cross-stream event wait costs the
-    // waiting stream 10-17 us even when the event has long fired (a barrier packet), which was a third of a 20-step
-    // call's fixed cost.  The buffer's stream carries the later chunks; if it still has work in flight (an ingest, a
+    // Chunk 0 is drawn and gathered on the TRAINER's stream, in front of its steps: handing it over from the buffer's
+    // stream put a cross-stream event wait and a second stream's launch latency in front of the first step (16 us of a
+    // 20-step call).  The buffer's stream carries the later chunks; if it still has work in flight (an ingest, a
     // random_batch nobody consumed) the trainer's stream waits for it first.
     if (hipStreamQuery(b->stream) != hipSuccess) {
         SAC_HIP(hipEventRecord(b->ev[3], b->stream));
@@ -2503,7 +2503,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     for (int c = 0; done < n_steps; ++c) {
         const int64_t first = done, want = loop_chunk_len(done);
         int64_t m = (n_steps - first < want) ? n_steps - first : want;
-        // (a tail shorter than half this chunk joins it: every chunk boundary is a cross-stream wait, ~10 us of idle stream)
+        // (a tail shorter than half this chunk joins it: every chunk boundary is a cross-stream wait)
         if (const int64_t rest = n_steps - first - m; rest > 0 && 2 * rest < m && m + rest <= LOOP_CH) m += rest;
         if (pos + m > LOOP_RING) pos = 0;
         const int e = c % sac_trainer::NLOOP_EV;
