@@ -260,7 +260,7 @@ def td3_main(args):
     print(json.dumps(out), flush=True)
 
 
-def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, fused=False):
+def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, fused=False, split=False):
     """Extra data point, never `value`: R independent runs (own buffer, nets, streams) driven from R host threads
     on ONE GPU -- the reference's real workload is 5 seeds x 29 configurations of independent jobs
     (/root/reference/launch_jobs.sh:15-24), and a single batch-256 run leaves most of the chip idle."""
@@ -268,7 +268,7 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, 
     # co-tenant runs: the fused step needs the whole chip to itself, so the replicas take the four-launch step -- unless
     # `fused`: then the library serialises their fused launches, and one run's weight-gradient launch (small blocks) can
     # share the chip with the next run's fused launch
-    if not fused:
+    if not fused and not split:
         os.environ["SAC_FUSED"] = "0"
     reps = [build_replica(task, O, A, B, 100_000, 100 + i, device) for i in range(n_replicas)]
     os.environ.pop("SAC_FUSED", None)
@@ -277,6 +277,13 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, 
         for i, (tr, buf) in enumerate(reps):
             _lib.check(tr._lib.sac_trainer_set_xcd(tr._h, i % 8), "sac_trainer_set_xcd")
             _lib.check(tr._lib.sac_buffer_set_xcd(buf._h, i % 8), "sac_buffer_set_xcd")
+    if split:           # experiment: the chip dealt out in equal shares of XCDs; a run whose fused step fits its share keeps it
+        from robosuite_benchmark_amd import _lib
+        per = max(1, 8 // n_replicas)
+        for i, (tr, buf) in enumerate(reps):
+            mask = ((1 << per) - 1) << (per * (i % (8 // per)))
+            _lib.check(tr._lib.sac_trainer_set_xcd_mask(tr._h, mask), "sac_trainer_set_xcd_mask")
+            _lib.check(tr._lib.sac_buffer_set_xcd_mask(buf._h, mask), "sac_buffer_set_xcd_mask")
     for tr, buf in reps:
         tr.train_loop(buf, 100, batch_size=B)
     t0 = time.perf_counter()
@@ -287,8 +294,10 @@ def concurrent_replicas(task, O, A, B, n_replicas, steps, device, by_xcd=False, 
         t.join()
     el = time.perf_counter() - t0
     return dict(replicas=n_replicas, steps_each=steps, value=round(n_replicas * steps / el, 2), unit="grad-steps/s",
-                placement="one XCD (32 CUs) per replica, CU-masked streams" if by_xcd else "every launch spans the chip",
-                step="fused (launches serialised across runs)" if fused and not by_xcd else "four launches",
+                placement=("%d XCDs per replica, CU-masked streams" % max(1, 8 // n_replicas)) if split else
+                "one XCD (32 CUs) per replica, CU-masked streams" if by_xcd else "every launch spans the chip",
+                step=("fused on its own XCDs" if all(tr.is_fused() for tr, _ in reps) else "four launches") if split else
+                "fused (launches serialised across runs)" if fused and not by_xcd else "four launches",
                 note="aggregate of independent runs sharing one GPU (100000-slot buffers); not the headline metric")
 
 
@@ -379,6 +388,8 @@ def main():
                     help="TD3: the SURVEY 8f row on the same workload shape (N=1, its own JSON line); default SAC = the headline metric")
     ap.add_argument("--xcd-replicas", action="store_true", help="with --replicas-per-gpu: confine replica i to XCD i % 8")
     ap.add_argument("--fused-replicas", action="store_true", help="with --replicas-per-gpu: the replicas keep the fused step")
+    ap.add_argument("--split-replicas", action="store_true",
+                    help="with --replicas-per-gpu R: replica i owns 8/R XCDs (CU-masked streams) and keeps the fused step if it fits them")
     ap.add_argument("--replicas-per-gpu", type=int, default=0,
                     help="N=1 only: also time R concurrent independent runs on the GPU (reported beside, never as, value)")
     args = ap.parse_args()
@@ -599,7 +610,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
                                   "(call returns) vs rows resident in HBM")
     if world == 1 and args.replicas_per_gpu > 1:
         out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device,
-                                                         by_xcd=args.xcd_replicas, fused=args.fused_replicas)
+                                                         by_xcd=args.xcd_replicas, fused=args.fused_replicas, split=args.split_replicas)
     return out
 
 

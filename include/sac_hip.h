@@ -249,9 +249,14 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float
 /* Experiment hooks (bench.py --replicas-per-gpu R --xcd-replicas): confine a handle's launches to
  * the CUs of one XCD (0..7) through a CU-masked stream, so that eight independent runs -- the reference's real workload is
  * many independent jobs, /root/reference/launch_jobs.sh:15-24 -- can share one GPU without each launch spanning the chip.
- * A trainer confined this way takes the four-launch step (the fused step needs every CU). */
+ * A trainer confined this way takes the four-launch step (the fused step needs all its workgroups resident).
+ * The _mask variants take a set of XCDs (bit k = XCD k): a trainer whose fused step fits the CUs it is given (batch 128
+ * on four XCDs) KEEPS the fused step and is no longer serialised with the other trainers of the process -- the caller
+ * promises that trainers confined this way own disjoint XCDs; mask 0xff undoes the confinement. */
 int sac_buffer_set_xcd(sac_buffer_t *buf, int xcd);
 int sac_trainer_set_xcd(sac_trainer_t *t, int xcd);
+int sac_buffer_set_xcd_mask(sac_buffer_t *buf, unsigned xcd_mask);
+int sac_trainer_set_xcd_mask(sac_trainer_t *t, unsigned xcd_mask);
 
 /* SURVEY.md 8d "Bounding roofline": the peaks the roofline fractions divide by, MEASURED on the box -- a float4
  * stream copy of 1 GiB (read + write GB/s) and a back-to-back v_mfma_f32_16x16x4_f32 loop on every SIMD (TFLOP/s).

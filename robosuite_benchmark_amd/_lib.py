@@ -100,6 +100,8 @@ SYMBOLS = {
     "sac_measure_peaks": (C.c_int, [C.c_int, _F]),
     "sac_buffer_set_xcd": (C.c_int, [_P, C.c_int]),
     "sac_trainer_set_xcd": (C.c_int, [_P, C.c_int]),
+    "sac_buffer_set_xcd_mask": (C.c_int, [_P, C.c_uint]),
+    "sac_trainer_set_xcd_mask": (C.c_int, [_P, C.c_uint]),
     "sac_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "sac_policy_mirror": (C.c_int, [_P]),
     "sac_policy_act": (C.c_int, [_P, _P, C.c_int, _P, _P]),

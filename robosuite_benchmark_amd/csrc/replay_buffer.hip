@@ -544,28 +544,37 @@ int sac_buffer_destroy(sac_buffer_t *b) {
     return 0;
 }
 
-// Stream of `xcd`'s CUs only (experiment: one independent run per XCD, bench.py --replicas-per-gpu).  CU-mask bits are
-// dealt round-robin over the 8 XCDs, so XCD k owns bits k, k + 8, k + 16, ...
-int sac_make_xcd_stream(hipStream_t *out, int xcd) {
+// Stream confined to the CUs of the XCDs in `xcd_mask` (bit k = XCD k; experiments: independent runs side by side on one
+// GPU, bench.py --replicas-per-gpu).  CU-mask bits are dealt round-robin over the 8 XCDs, so XCD k owns bits k, k + 8, ...
+int sac_make_xcd_mask_stream(hipStream_t *out, unsigned xcd_mask) {
     int cus = 0, dev = 0;
     SAC_HIP(hipGetDevice(&dev));
     SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    SAC_REQUIRE(xcd >= 0 && xcd < 8 && cus >= 8 && cus <= 512, "bad XCD index %d", xcd);
+    SAC_REQUIRE((xcd_mask & 0xffu) != 0 && (xcd_mask >> 8) == 0 && cus >= 8 && cus <= 512, "bad XCD mask 0x%x", xcd_mask);
     uint32_t mask[16] = {0};
-    for (int i = xcd; i < cus; i += 8) mask[i >> 5] |= 1u << (i & 31);
+    for (int i = 0; i < cus; ++i)
+        if ((xcd_mask >> (i & 7)) & 1u) mask[i >> 5] |= 1u << (i & 31);
     SAC_HIP(hipExtStreamCreateWithCUMask(out, (uint32_t)((cus + 31) / 32), mask));
     return 0;
 }
+int sac_make_xcd_stream(hipStream_t *out, int xcd) {
+    SAC_REQUIRE(xcd >= 0 && xcd < 8, "bad XCD index %d", xcd);
+    return sac_make_xcd_mask_stream(out, 1u << xcd);
+}
 
-int sac_buffer_set_xcd(sac_buffer_t *b, int xcd) {
+int sac_buffer_set_xcd_mask(sac_buffer_t *b, unsigned xcd_mask) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_HIP(hipSetDevice(b->device));
     SAC_HIP(hipStreamSynchronize(b->stream));
     hipStream_t ns = nullptr;
-    if (sac_make_xcd_stream(&ns, xcd)) return -1;
+    if (sac_make_xcd_mask_stream(&ns, xcd_mask)) return -1;
     SAC_HIP(hipStreamDestroy(b->stream));
     b->stream = ns;
     return 0;
+}
+int sac_buffer_set_xcd(sac_buffer_t *b, int xcd) {
+    SAC_REQUIRE(xcd >= 0 && xcd < 8, "bad XCD index %d", xcd);
+    return sac_buffer_set_xcd_mask(b, 1u << xcd);
 }
 
 int64_t sac_buffer_size(const sac_buffer_t *b) { return b ? b->size : -1; }

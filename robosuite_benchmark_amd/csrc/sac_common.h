@@ -141,6 +141,7 @@ struct sac_buffer {
 // slot of a live device batch (sac_random_batch_device token), or -1 with the error set (internal)
 extern "C" int sac_ring_slot_of(sac_buffer *b, int64_t token);
 extern "C" int sac_make_xcd_stream(hipStream_t *out, int xcd);
+extern "C" int sac_make_xcd_mask_stream(hipStream_t *out, unsigned xcd_mask);
 
 namespace sac {
 int ensure_stage(sac_buffer *b, size_t bytes);

@@ -1692,6 +1692,7 @@ struct sac_trainer {
     float *h_diag = nullptr, *d_diag_host = nullptr;  // mapped pinned: first[32] | last[32] (host view, device view)
     float last_ms[4] = {0, 0, 0, 0};
     bool loop_primed = false;
+    bool gate_exempt = false;                         // fused on CUs of its own (sac_trainer_set_xcd_mask): not serialised with other trainers
     bool timing_pending = false;                      // the last loop's event intervals have not been read yet (read lazily)
     hipEvent_t ev_tm[3] = {nullptr, nullptr, nullptr};  // around the draw and the gather of the loop's timed chunk
     std::vector<float> h_policy;                      // host mirror for acting
@@ -1865,7 +1866,7 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
         FusedGate &G = g_gate[t->device & 63];
         {
             std::lock_guard<std::mutex> lk(G.mu);
-            const bool gate = G.live > 1;
+            const bool gate = G.live > 1 && !t->gate_exempt;
             if (gate && G.last && G.last != s) SAC_HIP(hipStreamWaitEvent(s, G.ev, 0));
             hipLaunchKernelGGL(t->abc, dim3(16 * NB), dim3(256), t->lds_abc, s, d, S, SL, sa);
             if (gate) { SAC_HIP(hipEventRecord(G.ev, s)); G.last = s; }
@@ -1889,9 +1890,6 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     return 0;
 }
 
-// After the stream has drained: did a fused launch give up?  (Launch D of the first such step left the launch number in
-// the pinned diagnostics, applied nothing, and so did every step behind it.)  Roll the host counters back to the
-// applied steps, fall back to the four-launch step for good, and report.
 // Wait until everything launched on the trainer's stream so far has finished: a user-space poll (up to 2 ms) of an event
 // recorded behind it, then the blocking wait.  hipStreamSynchronize costs ~16 us even on a stream that is already idle
 // and its wake-up 10-20 us on one that is not -- a fifth of a single step, 2.5 % of a 20-step loop call.
@@ -1906,6 +1904,9 @@ static int wait_trainer_stream(sac_trainer *t, hipEvent_t recorded = nullptr) {
     return 0;
 }
 
+// After the stream has drained: did a fused launch give up?  (Launch D of the first such step left the launch number in
+// the pinned diagnostics, applied nothing, and so did every step behind it.)  Roll the host counters back to the
+// applied steps, fall back to the four-launch step for good, and report.
 int check_fused_abort(sac_trainer *t) {
     const unsigned launched = t->fused_unchecked;
     t->fused_unchecked = 0;
@@ -1921,11 +1922,12 @@ int check_fused_abort(sac_trainer *t) {
     t->h_diag[SAC_DIAG_N + 30] = t->h_diag[SAC_DIAG_N + 31] = 0.f;
     SAC_HIP(hipMemsetAsync(t->d_sync, 0, t->sync_bytes, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    {
+    if (!t->gate_exempt) {
         FusedGate &G = g_gate[t->device & 63];
         std::lock_guard<std::mutex> lk(G.mu);
         G.live -= 1;
     }
+    t->gate_exempt = false;
     sac::set_error("fused SAC step gave up: a hand-off between its workgroups timed out (is another process or kernel using "
                    "this GPU?).  The last %u step(s) of the call were NOT applied; this trainer now uses the four-launch "
                    "step (SAC_FUSED=0 selects it from the start)", lost);
@@ -2226,7 +2228,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     if (t->fused) {
         FusedGate &G = g_gate[t->device & 63];
         std::lock_guard<std::mutex> lk(G.mu);
-        G.live -= 1;
+        if (!t->gate_exempt) G.live -= 1;
         if (G.last == t->stream) G.last = nullptr;
     }
     (void)hipFree(t->arena);
@@ -2609,25 +2611,43 @@ int sac_sync(sac_trainer_t *t) {
     return check_fused_abort(t);
 }
 
-// Experiment (bench.py --replicas-per-gpu with --xcd-replicas): confine this trainer's launches to one XCD's CUs.  The
-// fused step needs the whole chip, so the trainer switches to the four-launch step.
-extern "C" int sac_make_xcd_stream(hipStream_t *out, int xcd);
-int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
+// Experiment (bench.py --replicas-per-gpu): confine this trainer's launches to the CUs of the XCDs in `xcd_mask` (bit k =
+// XCD k).  The fused step needs all its 16 * NB workgroups resident at once: a confined trainer keeps it only if its
+// CUs can hold them (batch 128 on half the chip) -- and then takes no part in the gate that serialises fused launches of
+// different trainers: the CALLER promises that confined fused trainers own disjoint XCDs.  Otherwise it switches to the
+// four-launch step.
+extern "C" int sac_make_xcd_mask_stream(hipStream_t *out, unsigned xcd_mask);
+int sac_trainer_set_xcd_mask(sac_trainer_t *t, unsigned xcd_mask) {
     SAC_REQUIRE(t != nullptr, "null trainer");
     SAC_HIP(hipSetDevice(t->device));
     SAC_HIP(hipStreamSynchronize(t->stream));
     hipStream_t ns = nullptr;
-    if (sac_make_xcd_stream(&ns, xcd)) return -1;
+    if (sac_make_xcd_mask_stream(&ns, xcd_mask)) return -1;
     SAC_HIP(hipStreamDestroy(t->stream));
     t->stream = ns;
+    int cus = 0;
+    SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
+    const int mine = (cus / 8) * __builtin_popcount(xcd_mask & 0xffu);
     if (t->fused) {
         FusedGate &G = g_gate[t->device & 63];
         std::lock_guard<std::mutex> lk(G.mu);
-        G.live -= 1;
-        t->fused = false;
-        t->dw.abort = nullptr;
+        if (!t->gate_exempt) G.live -= 1;
+        if (16 * t->NB <= mine && (xcd_mask & 0xffu) != 0xffu) {
+            t->gate_exempt = true;
+        } else if ((xcd_mask & 0xffu) == 0xffu) {
+            t->gate_exempt = false;
+            G.live += 1;
+        } else {
+            t->gate_exempt = false;
+            t->fused = false;
+            t->dw.abort = nullptr;
+        }
     }
     return 0;
+}
+int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
+    SAC_REQUIRE(xcd >= 0 && xcd < 8, "bad XCD index %d", xcd);
+    return sac_trainer_set_xcd_mask(t, 1u << xcd);
 }
 
 // 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step

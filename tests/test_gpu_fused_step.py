@@ -132,6 +132,51 @@ def test_two_fused_trainers_interleaved_from_one_thread():
     _same(b.state_dict(), ref.state_dict())
 
 
+def test_two_fused_trainers_side_by_side_on_disjoint_halves_of_the_chip():
+    """Batch 128 = 128 workgroups: a trainer confined to four XCDs (CU-masked stream, sac_trainer_set_xcd_mask) keeps the
+    fused step, two such trainers run CONCURRENTLY from two host threads without the cross-trainer gate -- and each
+    computes exactly what a run that has the chip to itself computes.  A share too small for the fused step (one XCD)
+    switches the trainer to the four-launch step, same results."""
+    import threading
+    from robosuite_benchmark_amd import _lib
+    O, A, B, steps = 42, 7, 128, 150
+    a, ref = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    b, _ = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    c, _ = _pair_of_hip(O, A, B, seed=2, noise_seed=3)
+    bufs = [_buffer(3000, O, A, 1) for _ in range(4)]
+    for x in bufs:
+        x.seed(7)
+    for tr, buf, mask in ((a, bufs[0], 0x0f), (b, bufs[1], 0xf0)):
+        _lib.check(tr._lib.sac_trainer_set_xcd_mask(tr._h, mask), "sac_trainer_set_xcd_mask")
+        _lib.check(buf._lib.sac_buffer_set_xcd_mask(buf._h, mask), "sac_buffer_set_xcd_mask")
+        assert tr.is_fused()
+    _lib.check(c._lib.sac_trainer_set_xcd_mask(c._h, 0x04), "sac_trainer_set_xcd_mask")
+    assert not c.is_fused()
+    errs = []
+
+    def run(tr, buf):
+        try:
+            tr.train_loop(buf, steps, batch_size=B)
+        except Exception as e:                       # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(a, bufs[0])), threading.Thread(target=run, args=(b, bufs[1]))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    c.train_loop(bufs[2], steps, batch_size=B)
+    ref.train_loop(bufs[3], steps, batch_size=B)
+    assert a.is_fused() and b.is_fused()             # nobody gave up
+    for t in (a, b, c):
+        _same(t.state_dict(), ref.state_dict())
+    _lib.check(a._lib.sac_trainer_set_xcd_mask(a._h, 0xff), "sac_trainer_set_xcd_mask")      # back to the whole chip
+    assert a.is_fused()
+    a.train_loop(bufs[0], 5, batch_size=B)
+    ref.train_loop(bufs[3], 5, batch_size=B)
+    _same(a.state_dict(), ref.state_dict())
+
+
 def test_a_lost_producer_ends_in_an_error_not_a_hang_and_nothing_is_applied():
     """Launch 3 of the loop loses one producer workgroup (test hook): its consumers give up after the hand-off timeout,
     launch D of that step and of every later one applies nothing, the call reports the error, the counters say two steps,
