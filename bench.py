@@ -509,7 +509,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     fl_all = flops_per_kernel(B, O, A)
     step_kernels = [k for k in prof if k.startswith("k_") and k not in ("k_gather", "k_mt_randint") and prof[k] > 0]
     # a fused launch carries the FLOPs of the launches it replaces ("k_fwd_abc" = a + b + c ...)
-    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_step": ("k_fwd_a", "k_fwd_b", "k_bwd", "k_dw_adam")}
+    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd")}
     fl = {k: (sum(fl_all[p] for p in fused_parts[k]) if k in fused_parts else fl_all[k]) for k in step_kernels}
     kern = {}
     for k, f in fl.items():
@@ -530,7 +530,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
     dom_ms = prof[dom] + boundary_ms
     achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc", "k_step": "k_abc"}.get(dom, dom), workload_tag(task, B))
+    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc"}.get(dom, dom), workload_tag(task, B))
     pk_m = peaks["fp32_mfma_tflops"] if peaks else None
     whole = sum(fl.values()) * value / world / 1e12
     out["roofline"] = dict(

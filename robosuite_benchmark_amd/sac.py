@@ -185,14 +185,12 @@ class SACTrainer:
         names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_bwd", "reserved", "k_dw_adam",
                  "event_pair", "steps_wall"]
         mode = self.fused_mode()
-        if mode:                     # the fused step: k_abc = launches A + B + C in one (the next two slots read 0) ...
+        if mode:                     # the fused step: k_abc = launches A + B + C in one (the next two slots read 0)
             names[2], names[3], names[4] = "k_fwd_abc", "fused_b", "fused_c"
-        if mode == 2:                # ... and, as the one-launch step, the weight-gradient / Adam phase as well
-            names[2], names[6] = "k_step", "fused_d"
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
     def fused_mode(self):
-        """0: four launches per step; 1: k_abc + k_dw_adam; 2: one launch per step (k_abc with its phase D)."""
+        """0: four launches per step; 1: the fused step, k_abc + k_dw_adam."""
         return int(self._lib.sac_trainer_is_fused(self._h)) if self._h is not None else 0
 
     def is_fused(self):
