@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             vb += b3b;                                                       // T2(s',a')
             vq += b3q;                                                       // Q_i(s,a)
             const float tq = fminf(va, vb) - alpha * in_c;
-            yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
+            yv = bellman_target(d.reward_scale, in_r, in_t, d.discount, tq);
             dq = (row0 + (int)threadIdx.x < d.Bt) ? 2.0f * (vq - yv) * invB : 0.f;
             s_dq[threadIdx.x] = dq;
         }
@@ -567,11 +567,12 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
                 float da1 = dap[0], da2 = dap[SP];
 #pragma unroll
                 for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
-                const float da = da1 * dq1 + da2 * dq2;
+                const float da = actor_da(da1, dq1, da2, dq2);
                 const float om = 1.0f - actv * actv;
-                dz = da * om + (alpha * invB) * (2.0f * actv * om / (om + TANH_EPS));
+                const float alpha_invB = __fmul_rn(alpha, invB);
+                dz = actor_dz(da, om, alpha_invB, actv);
                 const float stdv2 = expf(lsv);
-                dls = (dz * stdv2 * epv - alpha * invB) * okv;
+                dls = actor_dls(dz, stdv2, epv, alpha_invB, okv);
                 XH[lds_off(row, A + a, 64)] = dls;
                 XH[lds_off(row, a, 64)] = dz;
             }

@@ -490,6 +490,22 @@ __device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+// Scalar expressions of the step that contain TWO candidate multiplies for one fused multiply-add.  hipcc (fp-contract
+// =fast) picks one of them per call site, and which one depends on unrelated code around it -- the fused kernel and
+// the four-launch kernels then stop being bit-identical (seen in round 2: turning three stores of the fused kernel into
+// write-through stores changed the last bit of the policy's head gradient).  Spelled out here, used by both.
+__device__ __forceinline__ float bellman_target(float reward_scale, float r, float term, float discount, float tq) {
+    return fmaf(reward_scale, r, __fmul_rn(__fmul_rn(1.0f - term, discount), tq));
+}
+__device__ __forceinline__ float actor_da(float da1, float dq1, float da2, float dq2) { return fmaf(da1, dq1, __fmul_rn(da2, dq2)); }
+// d/dz of (alpha log_pi - min Q) through a = tanh(z): da (1 - a^2) + (alpha/B) 2 a (1 - a^2) / (1 - a^2 + eps)
+__device__ __forceinline__ float actor_dz(float da, float om, float alpha_invB, float act) {
+    return fmaf(da, om, __fmul_rn(alpha_invB, __fdiv_rn(__fmul_rn(__fmul_rn(2.0f, act), om), __fadd_rn(om, TANH_EPS))));
+}
+__device__ __forceinline__ float actor_dls(float dz, float stdv, float eps, float alpha_invB, float ok) {
+    return __fmul_rn(fmaf(__fmul_rn(dz, stdv), eps, -alpha_invB), ok);
+}
+
 // swizzled LDS row-block [16][KL] from row-major global rows (two sources concatenated), in two
 // phases: issue() puts the loads in flight early, commit() writes LDS once they are needed.
 // Thread (row = tid / 16, p = tid % 16) owns columns p, p + 16, ... of its row: no division, and every
@@ -1049,7 +1065,7 @@ __device__ __forceinline__ void critic_bwd_block(const Dev &d, const float *__re
         vb += b3b;                                                       // T2(s',a')
         vq += b3q;                                                       // Q_i(s,a)
         const float tq = fminf(va, vb) - alpha * in_c;
-        yv = d.reward_scale * in_r + (1.0f - in_t) * d.discount * tq;
+        yv = bellman_target(d.reward_scale, in_r, in_t, d.discount, tq);
         dq = (row0 + (int)threadIdx.x < d.Bt) ? 2.0f * (vq - yv) * invB : 0.f;
         s_dq[threadIdx.x] = dq;
     }
@@ -1178,12 +1194,13 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
             float da1 = dap[0], da2 = dap[SP];
 #pragma unroll
             for (int p = 1; p < SP; ++p) { da1 += dap[p]; da2 += dap[SP + p]; }      // fixed order
-            const float da = da1 * dq1 + da2 * dq2;
+            const float da = actor_da(da1, dq1, da2, dq2);
             const float om = 1.0f - act * act;
             if constexpr (MODE == M_SAC) {
-                dz = da * om + (alpha * invB) * (2.0f * act * om / (om + TANH_EPS));
+                const float alpha_invB = __fmul_rn(alpha, invB);
+                dz = actor_dz(da, om, alpha_invB, act);
                 const float stdv = expf(lsv);
-                dls = (dz * stdv * epv - alpha * invB) * okv;
+                dls = actor_dls(dz, stdv, epv, alpha_invB, okv);
                 XH[lds_off(row, A + a, 64)] = dls;
             } else {
                 dz = da * om;
