@@ -2539,16 +2539,27 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         if (c == 0) timed = (n_steps > m) ? 1 : 0;
         if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[0], q));
         if (launch_sample(b, t->Bt, m, pos * t->B, nullptr, q)) return -1;
-        if (c == 0) SAC_HIP(hipEventRecord(t->ev[0], s));           // start of the device span (behind the first launch: one call less in front of it)
         if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[1], q));
-        if (c == 0) SAC_HIP(hipEventRecord(b->ev[3], q));           // (the generator's state: see below)
         if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1, q))
             return -1;
         if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[2], q));
+        // Chunk 0's two bookkeeping events go BEHIND its gather: an event record between two dependent launches of a stream
+        // is a packet of its own there (the gather started 10.6 us after the draw had ended instead of ~2.5: rocprofv3
+        // timeline of a 20-step call).  ev[0]: start of the device span (sac_last_loop_ms; it now excludes chunk 0's draw +
+        // gather, ~12 us); b->ev[3]: the generator's state (see below -- chunk 1's draw has four steps of slack).
+        if (c == 0) { SAC_HIP(hipEventRecord(t->ev[0], s)); SAC_HIP(hipEventRecord(b->ev[3], q)); }
         if (c == 0) ht("chunk 0 draw + gather submitted");
         if (c > 0) {
+            // The chunk's slots must be gathered before its first step.  An in-stream wait for the buffer's stream costs the
+            // trainer's stream ~5-10 us of idle time between two steps even when the gather finished long ago (a 20-step call
+            // has one such boundary: 1.5 % of it).  The host is far ahead of the device, so it looks itself: once it has
+            // SEEN the gather's event complete, the steps need no dependency at all.  (Bounded: a gather that is itself
+            // waiting for slots takes the in-stream wait.)
             SAC_HIP(hipEventRecord(t->ev_ready[e], b->stream));
-            SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0));
+            const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
+            hipError_t st;
+            while ((st = hipEventQuery(t->ev_ready[e])) == hipErrorNotReady && std::chrono::steady_clock::now() < spin_until) { }
+            if (st != hipSuccess) { (void)hipGetLastError(); SAC_HIP(hipStreamWaitEvent(s, t->ev_ready[e], 0)); }
         }
         for (int64_t i = 0; i < m; ++i) {
             t->publish_diag = (first + i == n_steps - 1);
