@@ -103,6 +103,33 @@ __device__ __forceinline__ AlphaStep alpha_step_v(const Ctl *ctl, const float *p
     return r;
 }
 
+// Wide first layers (obs_dim > 112; Wipe: 379): recomputing the whole layer in each of the four column parts of a
+// row-block is 4 tiles x K/16 chunks x 4 MFMAs per wave and pass (Wipe: 384 MFMAs, ~6 us, twice per chain).  Here a part
+// computes ITS quarter of the layer -- this wave: tile `wave` of quarter `part`, one accumulator, the same MFMA sequence
+// per tile as the four-tile GEMM: bit-identical -- publishes the pre-activations z = acc + b as one 1-KB tile (MFMA C
+// layout, write-through) and, once the four parts of (chain, rb) have signalled, loads this wave's four tiles of the
+// whole layer (columns 64 wave + 16 t: quarter `wave`, tile t).  One in-launch hand-off (~1.3 us) for 3/4 of the MFMAs.
+// Returns false when the wait gave up.
+template <int D>
+__device__ __forceinline__ bool split_first_layer(WRing<1, D> &rq, const float *X0, int KLQ, int KS, float bq, float *zx_blk,
+                                                  unsigned *cnt, unsigned target, unsigned *abort_flag, int *s_ok, int part,
+                                                  f32x4 (&z)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 acc[1] = {};
+    gemm_ring<false, false>(rq, X0, KLQ, KS, acc);
+    f32x4 zq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zq[i] = acc[0][i] + bq;
+    st4_sc1(zx_blk + ((part * 4 + wave) * 64 + lane) * 4, zq);
+    handoff_publish(cnt);
+    if (threadIdx.x == 0) *s_ok = handoff_wait(cnt, target, abort_flag);
+    lds_barrier();
+    if (!*s_ok) return false;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) z[t] = ld4(zx_blk + ((wave * 4 + t) * 64 + lane) * 4);
+    return true;
+}
+
 template <int NTH, bool WIDE>
 __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
@@ -135,6 +162,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // chains, phase B), ac[rb] (critic chain, phase B incl. the actor tail), lp (row-block sums of log pi)
     unsigned *cnt_head = d.cnt, *cnt_qa = d.cnt + (size_t)2 * NB * CNT_STRIDE, *cnt_tq = d.cnt + (size_t)3 * NB * CNT_STRIDE,
              *cnt_ac = d.cnt + (size_t)4 * NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)5 * NB * CNT_STRIDE;
+    unsigned *cnt_zx = d.cnt + (size_t)(5 * NB + 2) * CNT_STRIDE;   // [6 chains][NB]: the exchange of the split first layers (WIDE)
     const unsigned seq = sa.seq;
     const bool own_s = isq && net == 0 && part == 0, own_n = !isq && net == 0 && part == 0;
     // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
@@ -155,14 +183,20 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const float *obs = S + ((!isq && net) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
         RowRegs<WIDE ? 32 : 8> rows;
         rows.issue(K0, obs, O, O, S + SL.off_act + (size_t)row0 * A, isq ? A : 0, A, d.KP);
-        WRing<4, WIDE ? RD : RD0> r0;
-        r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
+        WRing<4, WIDE ? 1 : RD0> r0;
+        WRing<1, 8> rq;                                       // WIDE: this wave's ONE tile of this part's quarter (split_first_layer)
         constexpr int PRE0 = 2;
-        if constexpr (WIDE) r0.fill(K0 >> 4);                 // (wide first layers: a refilling ring, as in k_fwd_a)
-        else r0.fill_part(K0 >> 4, 0, PRE0);
-        float bv0[4];
+        float bv0[4], bq = 0.f;
+        if constexpr (WIDE) {
+            rq.init(P + L0.offW, L0.Kp, 64 * part + 16 * wave, 16);
+            rq.fill(K0 >> 4);
+            bq = P[L0.offB + 64 * part + 16 * wave + c];
+        } else {
+            r0.init(P + L0.offW, L0.Kp, 64 * wave, 16);
+            r0.fill_part(K0 >> 4, 0, PRE0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
+            for (int t = 0; t < 4; ++t) bv0[t] = P[L0.offB + 64 * wave + 16 * t + c];
+        }
         SB();
         WRing<1, 8> r1;
         r1.init(P + L1.offW, H, n0, 16);
@@ -191,10 +225,20 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
         rows.commit(X0, KLQ, K0, O, d.KP, isq ? A : 0);
         lds_barrier();
-        {   // first layer, all 256 features (recomputed by the 4 blocks of this row-block)
+        if constexpr (WIDE) {   // first layer: this part's quarter, then the exchange with the other three parts
+            const int chain = isq ? net : 2 + net;
+            if (!split_first_layer(rq, X0, KLQ, K0 >> 4, bq, d.zx + (size_t)(chain * NB + rb) * (RB * H),
+                                   cnt_zx + (size_t)(chain * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag, &s_ok, part, zkeep)) return;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    keep1[t][i] = fmaxf(zkeep[t][i], 0.f);
+                    X1[lds_off(4 * g + i, 64 * wave + 16 * t + c, H)] = keep1[t][i];
+                }
+        } else {   // first layer, all 256 features (recomputed by the 4 blocks of this row-block)
             f32x4 acc[4] = {};
-            if constexpr (WIDE) gemm_ring(r0, X0, KLQ, K0 >> 4, acc);
-            else gemm_straight_pf(r0, X0, KLQ, K0 >> 4, acc, r1, H >> 4, PRE0);
+            gemm_straight_pf(r0, X0, KLQ, K0 >> 4, acc, r1, H >> 4, PRE0);
             // the critic chain keeps the PRE-activation z = W1 [s, a] + b in registers: the layer is linear in the action,
             // so phase B gets Q_i(s, a_new)'s first layer as z + W1[:, action chunk] (a_new - a)
 #pragma unroll
@@ -280,21 +324,39 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     }
     f32x4 acc0[4];
     float bv0b[4];
+    // (wide first layers: a refilling ring -- for the critic chain it starts AT the action chunk and walks one chunk; the
+    //  policy chains, whose target nets run the whole layer, split it over the four parts: split_first_layer)
+    const int so0 = (WIDE && isq) ? KS0 - 1 : 0, ks0 = (WIDE && isq) ? 1 : KS0;
+    WRing<4, WIDE ? RD : RD0> q0;
+    WRing<1, 8> rq2;
+    float bq2 = 0.f;
     if (isq) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc0[t] = zkeep[t]; bv0b[t] = 0.f; }
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (!WIDE) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bv0b[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+            for (int t = 0; t < 4; ++t) bv0b[t] = PQ[d.LQ[0].offB + 64 * wave + 16 * t + c];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv0b[t] = 0.f;
+        }
     }
-    // (wide first layers: a refilling ring -- for the critic chain it starts AT the action chunk and walks one chunk)
-    const int so0 = (WIDE && isq) ? KS0 - 1 : 0, ks0 = (WIDE && isq) ? 1 : KS0;
-    WRing<4, WIDE ? RD : RD0> q0;
-    q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, so0);
-    if constexpr (WIDE) q0.fill(ks0);
-    else q0.fill_part(KS0, 0, RD0, lo0);
+    if constexpr (WIDE) {
+        if (isq) {
+            q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, so0);
+            q0.fill(ks0);
+        } else {
+            rq2.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * part + 16 * wave, 16);
+            rq2.fill(KS0);
+            bq2 = PQ[d.LQ[0].offB + 64 * part + 16 * wave + c];
+        }
+    } else {
+        q0.init(PQ + d.LQ[0].offW, d.LQ[0].Kp, 64 * wave, 16, so0);
+        q0.fill_part(KS0, 0, RD0, lo0);
+    }
     WRing<1, 8> q1;
     q1.init(PQ + d.LQ[1].offW, H, n0, 16);
     q1.fill(H >> 4);
@@ -331,9 +393,22 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     }
     STAMP(0, 4);
     // ---- Q / target-Q net on cat(obs, action) ----
-    if constexpr (WIDE) gemm_ring(q0, X0, KLQ, ks0, acc0, so0);
-    else gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
-    hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
+    if constexpr (WIDE) {
+        if (isq) {
+            gemm_ring(q0, X0, KLQ, ks0, acc0, so0);
+            hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
+        } else {
+            if (!split_first_layer(rq2, X0, KLQ, KS0, bq2, d.zx + (size_t)((4 + net) * NB + rb) * (RB * H),
+                                   cnt_zx + (size_t)((4 + net) * NB + rb) * CNT_STRIDE, 4u * seq, d.abort_flag, &s_ok, part, acc0)) return;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) X1[lds_off(4 * g + i, 64 * wave + 16 * t + c, H)] = fmaxf(acc0[t][i], 0.f);
+        }
+    } else {
+        gemm_straight(q0, X0, KLQ, KS0, acc0, lo0);
+        hidden_epilogue<4>(acc0, 64 * wave, 16, bv0b, X1, H, keep1);
+    }
     WRing<1, 4> ra;                                          // W1^T action rows: this wave's 64 first-hidden features
     if (isq) {
         SB();

@@ -107,6 +107,10 @@ struct Dev {
     // the sticky abort word (a wait timed out)
     float *qpart2, *logpi2p;
     float *hv4;                    // fused step: {a_new, log_std, eps, clamp mask} of a (row, action) as ONE 16-byte value [B][16][4]
+    // fused step, wide first layers: the four column parts of a row-block compute a quarter of the first layer each and
+    // exchange the pre-activations: zx[chain][rb][part][wave] = one 16 x 16 tile (1 KB, MFMA C layout); chains 0,1 =
+    // Q1,Q2(s,a), 2,3 = pi(s), pi(s'), 4,5 = T1,T2(s',a')
+    float *zx;
     unsigned *cnt, *abort_flag;
     // diagnostics
     float *diag_first, *diag_last, *diag_trace;      // first / last: mapped pinned host memory; trace: device
@@ -278,7 +282,8 @@ struct WRing {
 // with row stride WLD (this wave's tile t owns columns 16 t ..), for a later contraction over the rows of W
 // (gemm_lds_rows) -- the same bytes a backward pass would otherwise fetch again from the transposed copy.
 constexpr int WLD = 64 + 4;       // 64 staged weight rows; +4: scatter writes and 16-B reads are bank-conflict free
-template <bool STAGED = false, int NT, int D>
+// ALT = false: a one-tile GEMM accumulates in ONE register like a tile of a four-tile GEMM does (bit-identical to it).
+template <bool STAGED = false, bool ALT = true, int NT, int D>
 __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int KL, int KS, f32x4 (&acc)[NT],
                                           int s_off = 0, float *stage = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -306,7 +311,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
                 SB();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if constexpr (NT == 1) {
+                    if constexpr (NT == 1 && ALT) {
                         // one tile per wave = one dependency chain: consecutive MFMAs alternate between two accumulators
                         // (a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32)
                         if (i & 1) acc_odd = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], R.b[u][0][i], acc_odd, 0, 0, 0);
@@ -327,7 +332,7 @@ __device__ __forceinline__ void gemm_ring(WRing<NT, D> &R, const float *X, int K
             }
         }
     }
-    if constexpr (NT == 1) acc[0] += acc_odd;
+    if constexpr (NT == 1 && ALT) acc[0] += acc_odd;
 }
 
 // acc[t] += X[16 x 16*KS] * W[16*KS rows][16 columns at col0 + 16 t] from the slice staged by gemm_ring
@@ -2072,7 +2077,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         {&d.QH1T, 4LL * H * B}, {&d.QH2T, 4LL * H * B}, {&d.q, 6LL * B}, {&d.QU, 2LL * H * B},
         {&d.y, B}, {&d.dq16T, 2LL * 16 * B}, {&d.dQH2T, 2LL * H * B}, {&d.dQH1T, 2LL * H * B},
         {&d.headpart, 2LL * t->NB * 4 * RB * 32}, {&d.qpart, 6LL * 4 * B}, {&d.dapart, 2LL * 4 * B * 16},
-        {&d.qpart2, 6LL * t->NB * 4 * 32}, {&d.logpi2p, 32LL * t->NB}, {&d.hv4, 64LL * B},
+        {&d.qpart2, 6LL * t->NB * 4 * 32}, {&d.logpi2p, 32LL * t->NB}, {&d.hv4, 64LL * B}, {&d.zx, 6LL * H * B},
         {&d.dheadT, (long long)t->NH * B}, {&d.dPH2T, (long long)H * B}, {&d.dPH1T, (long long)H * B}};
     long long tot = 0;
     for (auto &p : parts) tot += round_up64(p.second, 64);
@@ -2083,7 +2088,8 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     if (alloc_zero(&t->d_eps, 2LL * B * t->A, s)) return -1;
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
     arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
-    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (5 * t->NB + 2);     // head[2][NB], qa / tq / ac [NB], log-pi, abort
+    // head[2][NB], qa / tq / ac [NB], log-pi, abort; then zx[6][NB] (the exchange of the split first layers)
+    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (5 * t->NB + 2 + 6 * t->NB);
     arena.reserve(reinterpret_cast<void **>(&t->d_sync), t->sync_bytes);
     arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW * 3);
     g_arena = nullptr;
