@@ -2174,7 +2174,9 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     t->lds_fb = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * sw + 1024 + (t->SP == 4 ? H * WLD : 0));
     t->lds_bw = sizeof(float) * (size_t)(RB * 64 + RB * H);
     SAC_REQUIRE(t->lds_fa <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
-    const bool wide = t->KQ > 16 * RD0;
+    int wide_min = 16 * RD0 + 1;                       // (SAC_WIDE_MIN_KQ: tuning experiments only)
+    if (const char *e = getenv("SAC_WIDE_MIN_KQ")) wide_min = atoi(e);
+    const bool wide = t->KQ >= wide_min;
 #define SAC_PICK(SPV)                                                                                      \
     do {                                                                                                   \
         t->fwd_a = (nth == 1) ? (wide ? &k_fwd_a<1, true, SPV> : &k_fwd_a<1, false, SPV>)                   \
