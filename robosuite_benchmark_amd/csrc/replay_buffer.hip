@@ -356,7 +356,25 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
 
 // `batch` indices per batch, stored at a stride of round_up(batch, 16).  dst == null: into b->d_idx + idx_offset
 // (idx_offset in elements of that padded layout; the buffer is grown as needed when idx_offset == 0).
+int readahead_rollback(sac_buffer *b) {
+    b->ra_streak = 0;
+    if (b->ra_ahead <= 0) return 0;
+    const int consumed = b->ra_chunk - (int)b->ra_ahead;
+    // the speculative batches that nobody asked for: their slots hold no batch any more
+    for (int64_t j = 0; j < b->ra_ahead; ++j) b->ring_token[(b->ring_next + j) % sac_buffer::NRING] = -1;
+    b->ra_ahead = 0;
+    SAC_HIP(hipMemcpyAsync(b->d_rng, b->d_rng_saved, sizeof(MtState), hipMemcpyDeviceToDevice, b->stream));
+    if (consumed > 0) {      // the generator as `consumed` random_batch calls leave it (the indices themselves are not needed)
+        b->ra_internal = true;
+        const int rc = launch_sample(b, b->ra_batch, consumed, 0, b->d_ra_scratch, b->stream);
+        b->ra_internal = false;
+        if (rc) return -1;
+    }
+    return 0;
+}
+
 int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst, hipStream_t on) {
+    if (!b->ra_internal && readahead_rollback(b)) return -1;
     hipStream_t q = on ? on : b->stream;
     const int bp = round_up(batch, RB);
     const int64_t count = (int64_t)batch * n_batches, padded = (int64_t)bp * n_batches;
@@ -458,6 +476,7 @@ static int add_impl(sac_buffer *b, int64_t n, const Src *obs, const Src *act, co
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_REQUIRE(n >= 0 && obs && act && rew && nobs && term, "bad arguments to sac_buffer_add");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;        // (batches gathered ahead saw the old rows and the old size)
     const int O = b->O, A = b->A;
     int64_t i = 0;
     if (n > b->capacity) {      // only the last `capacity` samples survive; keep ring arithmetic exact
@@ -535,6 +554,7 @@ int sac_buffer_destroy(sac_buffer_t *b) {
         if (b->ing_free[k]) (void)hipEventDestroy(b->ing_free[k]);
     }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_ring_idx);
+    (void)hipFree(b->d_rng_saved); (void)hipFree(b->d_ra_scratch);
     for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ring_free) if (e) (void)hipEventDestroy(e);
@@ -644,6 +664,8 @@ int sac_buffer_set_cursor(sac_buffer_t *b, int64_t top, int64_t size) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_REQUIRE(top >= 0 && top < b->capacity && size >= 0 && size <= b->capacity, "bad cursor (top %lld, size %lld)",
                 (long long)top, (long long)size);
+    SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;
     if (size < b->size) {      // pad entries of the index buffers must stay valid rows: back to row 0
         SAC_HIP(hipSetDevice(b->device));
         if (b->d_idx) SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * b->idx_cap, b->stream));
@@ -657,6 +679,7 @@ int sac_buffer_set_cursor(sac_buffer_t *b, int64_t top, int64_t size) {
 int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;
     MtState s;
     memset(&s, 0, sizeof(s));
     s.mt[0] = seed;
@@ -670,6 +693,7 @@ int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
 int sac_rng_get_state(sac_buffer_t *b, uint32_t key[624], int32_t *pos) {
     SAC_REQUIRE(b && key && pos, "bad arguments to sac_rng_get_state");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;        // (the state a caller sees is the state behind the batches it was GIVEN)
     MtState s;
     SAC_HIP(hipMemcpyAsync(&s, b->d_rng, sizeof(s), hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
@@ -681,6 +705,7 @@ int sac_rng_get_state(sac_buffer_t *b, uint32_t key[624], int32_t *pos) {
 int sac_rng_set_state(sac_buffer_t *b, const uint32_t key[624], int32_t pos) {
     SAC_REQUIRE(b && key && pos >= 0 && pos <= MT_N, "bad arguments to sac_rng_set_state");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;
     MtState s;
     memset(&s, 0, sizeof(s));
     memcpy(s.mt, key, sizeof(uint32_t) * MT_N);
@@ -730,6 +755,7 @@ int sac_random_batch(sac_buffer_t *b, int batch, float *obs, float *act, float *
 // ---- device-resident batches (the stepwise interface without a PCIe round trip per step) ----------------
 static int ensure_ring(sac_buffer *b, int batch) {
     if (b->d_ring && b->ring_layout.Bt == batch) return 0;
+    if (readahead_rollback(b)) return -1;
     SAC_HIP(hipStreamSynchronize(b->stream));
     if (b->d_ring) { SAC_HIP(hipFree(b->d_ring)); SAC_HIP(hipFree(b->d_ring_idx)); b->d_ring = nullptr; b->d_ring_idx = nullptr; }
     b->ring_layout = make_slot_layout(batch, b->O, b->A);
@@ -738,8 +764,17 @@ static int ensure_ring(sac_buffer *b, int batch) {
     SAC_HIP(hipMemsetAsync(b->d_ring, 0, sizeof(float) * nfl, b->stream));    // saT padding rows stay 0
     SAC_HIP(hipMalloc(&b->d_ring_idx, sizeof(int64_t) * (size_t)b->ring_layout.B * sac_buffer::NRING));
     SAC_HIP(hipMemsetAsync(b->d_ring_idx, 0, sizeof(int64_t) * (size_t)b->ring_layout.B * sac_buffer::NRING, b->stream));
+    if (!b->d_rng_saved) SAC_HIP(hipMalloc(&b->d_rng_saved, sizeof(MtState)));
+    if (b->ra_scratch_cap < (int64_t)b->ring_layout.B * sac_buffer::RA_MAX) {
+        if (b->d_ra_scratch) SAC_HIP(hipFree(b->d_ra_scratch));
+        b->ra_scratch_cap = (int64_t)b->ring_layout.B * sac_buffer::RA_MAX;
+        SAC_HIP(hipMalloc(&b->d_ra_scratch, sizeof(int64_t) * b->ra_scratch_cap));
+    }
+    if (const char *e = getenv("SAC_READAHEAD")) b->ra_enabled = atoi(e) != 0;
+    b->waited_chunk_token = -1; b->waited_stream = nullptr;
     for (int i = 0; i < sac_buffer::NRING; ++i) {
         b->ring_token[i] = -1; b->ring_in_use[i] = false;
+        b->ring_first[i] = i; b->ring_chunk_token[i] = -1;
         if (!b->ring_ready[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_ready[i], hipEventDisableTiming));
         if (!b->ring_free[i]) SAC_HIP(hipEventCreateWithFlags(&b->ring_free[i], hipEventDisableTiming));
     }
@@ -751,35 +786,65 @@ static int ensure_ring(sac_buffer *b, int batch) {
     return 0;
 }
 
+// the slot's previous batch may still be read by a step in flight on a trainer's stream: the buffer's stream waits
+static int wait_slot_free(sac_buffer *b, int slot) {
+    if (!b->ring_in_use[slot]) return 0;
+    if (b->multi_stream) {
+        SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
+    } else if (b->free_waited_seq < b->slot_seq[slot]) {
+        const int64_t m = b->slot_seq[slot] | 7;
+        const int idx = (int)((m >> 3) & 3);
+        if (b->free4_seq[idx] == m) {                   // the usual case: recorded ~24 steps ago, long fired
+            SAC_HIP(hipStreamWaitEvent(b->stream, b->free4[idx], 0));
+            b->free_waited_seq = m;
+        } else {                                        // no event at or behind that step yet: record one now
+            SAC_HIP(hipEventRecord(b->ring_free[slot], b->step_stream));
+            SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
+            b->free_waited_seq = b->step_seq - 1;
+        }
+    }
+    b->ring_in_use[slot] = false;
+    return 0;
+}
+
 int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     SAC_REQUIRE(b && batch > 0 && token, "bad arguments to sac_random_batch_device");
     SAC_HIP(hipSetDevice(b->device));
     if (ensure_ring(b, batch)) return -1;
     const int64_t n = b->ring_next;
     const int slot = (int)(n % sac_buffer::NRING);
-    // the slot's previous batch may still be read by a step in flight on a trainer's stream
-    if (b->ring_in_use[slot]) {
-        if (b->multi_stream) {
-            SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
-        } else if (b->free_waited_seq < b->slot_seq[slot]) {
-            const int64_t m = b->slot_seq[slot] | 3;
-            const int idx = (int)((m >> 2) & 3);
-            if (b->free4_seq[idx] == m) {                   // the usual case: recorded ~12 steps ago, long fired
-                SAC_HIP(hipStreamWaitEvent(b->stream, b->free4[idx], 0));
-                b->free_waited_seq = m;
-            } else {                                        // no event at or behind that step yet: record one now
-                SAC_HIP(hipEventRecord(b->ring_free[slot], b->step_stream));
-                SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
-                b->free_waited_seq = b->step_seq - 1;
-            }
-        }
-        b->ring_in_use[slot] = false;
+    if (b->ra_ahead > 0) {                   // drawn and gathered ahead by an earlier call: hand it out
+        b->ra_ahead -= 1;
+        b->ra_streak += 1;
+        b->ring_next = n + 1;
+        *token = n;
+        return 0;
     }
+    // how many batches this call draws: 1 until the caller has asked twice in a row with nothing in between, then 2, 4, 8
+    // (never across the end of the ring: the chunk's slots and indices are contiguous)
+    int k = 1;
+    if (b->ra_enabled && !b->multi_stream) {
+        k = b->ra_streak >= 8 ? 8 : (b->ra_streak >= 4 ? 4 : (b->ra_streak >= 2 ? 2 : 1));
+        if (k > sac_buffer::RA_MAX) k = sac_buffer::RA_MAX;
+        if (k > sac_buffer::NRING - slot) k = sac_buffer::NRING - slot;
+    }
+    for (int j = 0; j < k; ++j)
+        if (wait_slot_free(b, slot + j)) return -1;
     int64_t *didx = b->d_ring_idx + (size_t)slot * b->ring_layout.B;
-    if (launch_sample(b, batch, 1, 0, didx)) return -1;
-    if (launch_gather(b, didx, b->ring_layout.B, 1, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;
+    if (k > 1) SAC_HIP(hipMemcpyAsync(b->d_rng_saved, b->d_rng, sizeof(MtState), hipMemcpyDeviceToDevice, b->stream));
+    b->ra_internal = true;
+    const int rc = launch_sample(b, batch, k, 0, didx);
+    b->ra_internal = false;
+    if (rc) return -1;
+    if (launch_gather(b, didx, b->ring_layout.B, k, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 1)) return -1;
     SAC_HIP(hipEventRecord(b->ring_ready[slot], b->stream));
-    b->ring_token[slot] = n;
+    for (int j = 0; j < k; ++j) {
+        b->ring_token[slot + j] = n + j;
+        b->ring_first[slot + j] = slot;
+        b->ring_chunk_token[slot + j] = n;
+    }
+    b->ra_chunk = k; b->ra_batch = batch; b->ra_ahead = k - 1;
+    b->ra_streak += 1;
     b->ring_next = n + 1;
     *token = n;
     return 0;

@@ -118,21 +118,39 @@ struct sac_buffer {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // device-resident batches of the stepwise interface (sac_random_batch_device): a ring of NRING slots; batch
     // number n lives in slot n % NRING until batch n + NRING is drawn
-    static constexpr int NRING = 16;
+    static constexpr int NRING = 32;                 // (a token stays valid until 16 more batches have been DRAWN: 32 - RA_MAX - 8)
     float *d_ring = nullptr; int64_t *d_ring_idx = nullptr;
     sac::SlotLayout ring_layout{};
     int64_t ring_next = 0;                           // number of batches drawn so far
     int64_t ring_token[NRING];                       // batch number held by each slot (-1: none)
     hipEvent_t ring_ready[NRING] = {}, ring_free[NRING] = {};
     bool ring_in_use[NRING] = {};                    // a step was launched on the slot and nobody has waited for it since
-    // "the trainer is done with this slot" is signalled by ONE event per four steps (two runtime calls per step was a
-    // fifth of the stepwise interface's host time): step k (launch sequence) leaves its number in the slot, every fourth
-    // step records free4[(k >> 2) & 3]; a draw that reuses a slot waits for the oldest event recorded at or behind the
+    // "the trainer is done with this slot" is signalled by ONE event per eight steps (two runtime calls per step was a
+    // fifth of the stepwise interface's host time): step k (launch sequence) leaves its number in the slot, every eighth
+    // step records free4[(k >> 3) & 3]; a draw that reuses a slot waits for the oldest event recorded at or behind the
     // slot's step (the per-slot event ring_free[] is the fall-back when no such event exists)
     hipEvent_t free4[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t free4_seq[4] = {-1, -1, -1, -1};
     int64_t step_seq = 0, free_waited_seq = -1;
     int64_t slot_seq[NRING] = {};
+    // Read-ahead of the stepwise interface: when random_batch_device is called again and again with nothing in between that
+    // touches the generator or the buffer (the reference's loop: rlkit_custom.py:234-238), the call draws and gathers the
+    // next RA batches too, in the same two launches, and the following calls just hand them out.  Anything that reads or
+    // changes the generator, the buffer's rows or its size first ROLLS the speculation BACK: the generator's state saved
+    // in front of the chunk is restored and advanced by the batches that were handed out (one small draw), so the index
+    // stream stays NumPy's, bit for bit, whatever the caller interleaves.
+    static constexpr int RA_MAX = 8;
+    int64_t ra_ahead = 0;                            // batches drawn + gathered beyond ring_next
+    int ra_chunk = 0, ra_batch = 0;                  // size of the chunk they belong to; the batch size it was drawn for
+    int ra_streak = 0;                               // consecutive random_batch_device calls with nothing in between
+    bool ra_internal = false;                        // (a draw of the read-ahead itself is in progress)
+    bool ra_enabled = true;
+    sac::MtState *d_rng_saved = nullptr;
+    int64_t *d_ra_scratch = nullptr; int64_t ra_scratch_cap = 0;
+    int ring_first[NRING] = {};                      // slot whose ring_ready event covers this slot (first of its chunk)
+    int64_t ring_chunk_token[NRING] = {};            // token of that first batch
+    hipStream_t waited_stream = nullptr;             // the step stream has already waited for chunks up to waited_chunk_token
+    int64_t waited_chunk_token = -1;
     hipStream_t step_stream = nullptr;               // the stream the steps are launched on (one trainer per buffer; a second
     bool multi_stream = false;                       // stream switches to one event per step)
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
@@ -152,4 +170,7 @@ int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offse
                   hipStream_t on = nullptr);
 int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batches, float *d_slots,
                   const SlotLayout &L, int write_saT, hipStream_t on = nullptr);
+// undo the stepwise interface's read-ahead (see sac_buffer::ra_ahead); to be called in front of anything that reads or
+// changes the generator's state, the buffer's rows or its size
+int readahead_rollback(sac_buffer *b);
 }  // namespace sac

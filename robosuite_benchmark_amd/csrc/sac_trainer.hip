@@ -1958,6 +1958,7 @@ int check_fused_abort(sac_trainer *t) {
 
 // sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
 int stage_batches(sac_trainer *t, sac_buffer *b, int64_t n_steps) {
+    if (readahead_rollback(b)) return -1;
     if (ensure_slots(b, t->Bt, n_steps)) return -1;
     SAC_HIP(hipEventRecord(b->ev[0], b->stream));
     if (launch_sample(b, t->Bt, n_steps)) return -1;
@@ -2426,7 +2427,14 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     SAC_REQUIRE(b->ring_layout.Bt == t->Bt, "device batch holds %d rows, the trainer was created for %d", b->ring_layout.Bt, t->Bt);
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
-    SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[slot], 0));
+    // one event per CHUNK of batches the buffer drew and gathered together (read-ahead, sac_random_batch_device): a step on
+    // a later batch of a chunk this stream has already waited for needs no wait of its own (an in-stream wait costs the
+    // stream ~3 us even when its event fired long ago)
+    if (b->multi_stream || b->waited_stream != s || b->ring_chunk_token[slot] > b->waited_chunk_token) {
+        SAC_HIP(hipStreamWaitEvent(s, b->ring_ready[b->ring_first[slot]], 0));
+        b->waited_stream = s;
+        b->waited_chunk_token = b->ring_chunk_token[slot];
+    }
     t->dev.eps1 = t->dev.eps2 = nullptr;
     t->publish_diag = diag != nullptr;
     const int rc_step = launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr);
@@ -2438,7 +2446,7 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
         const int64_t k = b->step_seq++;
         b->slot_seq[slot] = k;
         if (b->multi_stream) SAC_HIP(hipEventRecord(b->ring_free[slot], s));
-        else if ((k & 3) == 3) { SAC_HIP(hipEventRecord(b->free4[(k >> 2) & 3], s)); b->free4_seq[(k >> 2) & 3] = k; }
+        else if ((k & 7) == 7) { SAC_HIP(hipEventRecord(b->free4[(k >> 3) & 3], s)); b->free4_seq[(k >> 3) & 3] = k; }   // (one per EIGHT steps: 4 events cover the ring of 32)
         b->ring_in_use[slot] = true;
     }
     t->mirror_valid = false;
@@ -2502,6 +2510,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
+    if (readahead_rollback(b)) return -1;          // (batches the stepwise interface drew ahead: the generator goes back first)
     if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
     if (ensure_idx(b, LOOP_RING * t->B)) return -1;
     ht("set-up done");

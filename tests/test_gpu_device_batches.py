@@ -76,14 +76,79 @@ def test_expired_device_batch_is_refused_not_wrong():
     buf = filled(500, O, A, 4)
     buf.seed(1)
     old = buf.random_batch(B)
-    keep = [buf.random_batch(B) for _ in range(16)]         # the ring holds 16 batches
+    keep = [buf.random_batch(B) for _ in range(40)]         # the ring holds 32 batches (some of them drawn ahead)
     with pytest.raises(RuntimeError, match="expired"):
         old["observations"]
     with pytest.raises(RuntimeError, match="expired"):
         tr.train(old)
-    assert keep[-1]["actions"].shape == (B, A) and keep[0]["rewards"].shape == (B, 1)
+    # a batch stays valid until (at least) 16 more have been drawn
+    assert keep[-1]["actions"].shape == (B, A) and keep[-17]["rewards"].shape == (B, 1)
     other = EnvReplayBuffer(500, obs_dim=O + 1, action_dim=A)
     other.add_block(np.zeros((10, O + 1), np.float32), np.zeros((10, A), np.float32), np.zeros(10, np.float32),
                     np.zeros((10, O + 1), np.float32), np.zeros(10, np.uint8))
     with pytest.raises(RuntimeError, match="does not match"):
         tr.train(other.random_batch(B))
+
+
+def test_read_ahead_keeps_numpys_stream_and_the_buffers_rows_under_any_interleaving():
+    """random_batch draws and gathers up to eight batches ahead once it is called repeatedly (sac_random_batch_device);
+    whatever else the caller does in between -- inserts, other batch sizes, reading or setting the generator, host batches,
+    index draws, a fused loop -- the indices stay NumPy's and the rows the buffer's at the time of the call."""
+    O, A, cap = 9, 3, 20000
+    rs_data = np.random.RandomState(5)
+    obs = rs_data.normal(size=(cap, O)).astype(np.float32)
+    act = rs_data.uniform(-1, 1, (cap, A)).astype(np.float32)
+    rew = rs_data.uniform(0, 1, (cap, 1)).astype(np.float32)
+    nobs = rs_data.normal(size=(cap, O)).astype(np.float32)
+    term = np.zeros((cap, 1), np.uint8)
+    buf = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)
+    size = 3000
+    buf.add_block(obs[:size], act[:size], rew[:size], nobs[:size], term[:size])
+    buf.seed(99)
+    ref = np.random.RandomState(99)
+    _, tr = make_pair(O, A, 48, seed=2)
+    script = np.random.RandomState(7)
+    pending = []                                             # device batches not looked at yet: (batch, expected indices)
+
+    def check(db, want):
+        assert np.array_equal(db.indices(), want)
+        assert np.array_equal(db["observations"], obs[want]) and np.array_equal(db["rewards"], rew[want])
+
+    for it in range(400):
+        r = script.randint(0, 100)
+        if r < 70:                                           # the common case: the next batch
+            B = 48 if r < 64 else 33
+            if pending and pending[-1][0]._batch_size != B:  # (another batch size re-creates the ring: its batches expire)
+                while pending:
+                    check(*pending.pop(0))
+            pending.append((buf.random_batch(B), ref.randint(0, size, B)))
+        elif r < 78:                                         # an insert: batches drawn ahead saw the old size
+            n = int(script.randint(1, 40))
+            buf.add_block(obs[size:size + n], act[size:size + n], rew[size:size + n], nobs[size:size + n], term[size:size + n])
+            size += n
+        elif r < 83:                                         # the generator, read ...
+            key, pos = buf.rng_state()
+            st = ref.get_state()
+            assert pos == st[2] and np.array_equal(key, st[1])
+        elif r < 86:                                         # ... and set
+            ref = np.random.RandomState(int(script.randint(0, 1 << 30)))
+            buf.seed_from_numpy(ref)
+        elif r < 91:                                         # a host batch
+            b, idx = buf.random_batch(20, return_indices=True)
+            want = ref.randint(0, size, 20)
+            assert np.array_equal(idx, want) and np.array_equal(b["actions"], act[want])
+        elif r < 95:                                         # bare index draws
+            got = buf.sample_indices(17, 3)
+            for k in range(3):
+                assert np.array_equal(got[k], ref.randint(0, size, 17))
+        else:                                                # a fused loop of a few steps consumes the stream too
+            tr.train_loop(buf, 3, batch_size=48)
+            for _ in range(3):
+                ref.randint(0, size, 48)
+        while len(pending) > 12 or (pending and script.randint(0, 4) == 0):
+            check(*pending.pop(0))
+    for p in pending:
+        check(*p)
+    key, pos = buf.rng_state()
+    st = ref.get_state()
+    assert pos == st[2] and np.array_equal(key, st[1])
