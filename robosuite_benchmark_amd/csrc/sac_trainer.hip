@@ -2564,7 +2564,12 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         // is a packet of its own there (the gather started 10.6 us after the draw had ended instead of ~2.5: rocprofv3
         // timeline of a 20-step call).  ev[0]: start of the device span (sac_last_loop_ms; it now excludes chunk 0's draw +
         // gather, ~12 us); b->ev[3]: the generator's state (see below -- chunk 1's draw has four steps of slack).
-        if (c == 0) { SAC_HIP(hipEventRecord(t->ev[0], s)); SAC_HIP(hipEventRecord(b->ev[3], q)); }
+        // (a single-chunk call needs no b->ev[3]: nothing is drawn on the buffer's stream during the call, and the call
+        //  returns behind a drained stream.  It must not leave a wait on the buffer's stream either: the NEXT call's
+        //  hipStreamQuery then reports that stream busy and pays two runtime calls plus an in-stream wait in front of its
+        //  first launch -- ~30 us of the first 20-step call behind single-step calls.)
+        const bool more_chunks = m < n_steps;
+        if (c == 0) { SAC_HIP(hipEventRecord(t->ev[0], s)); if (more_chunks) SAC_HIP(hipEventRecord(b->ev[3], q)); }
         if (c == 0) ht("chunk 0 draw + gather submitted");
         if (c > 0) {
             // The chunk's slots must be gathered before its first step.  An in-stream wait for the buffer's stream costs the
@@ -2584,11 +2589,15 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         }
         // the generator's state is one in-order sequence: everything later on the buffer's stream follows chunk 0's draw
         // (told to that stream only now, behind chunk 0's step launches: nothing of it is in front of the first step)
-        if (c == 0) SAC_HIP(hipStreamWaitEvent(b->stream, b->ev[3], 0));
+        if (c == 0 && more_chunks) SAC_HIP(hipStreamWaitEvent(b->stream, b->ev[3], 0));
         t->publish_diag = true;
-        SAC_HIP(hipEventRecord(t->ev_done[e], s));
-        SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV + 4, "internal: loop chunk bookkeeping overflow");
-        live[n_live++] = Live{pos, m, e};
+        // "the trainer is done with this chunk's slots": only a call that wraps the slot ring ever asks (the next call
+        // starts behind a drained stream) -- a short call keeps these records out of its stream (~2-5 us each)
+        if (n_steps > LOOP_RING) {
+            SAC_HIP(hipEventRecord(t->ev_done[e], s));
+            SAC_REQUIRE(n_live < sac_trainer::NLOOP_EV + 4, "internal: loop chunk bookkeeping overflow");
+            live[n_live++] = Live{pos, m, e};
+        }
         pos += m;
         done += m;
     }
