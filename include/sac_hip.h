@@ -98,7 +98,7 @@ int sac_random_batch(sac_buffer_t *buf, int batch, float *obs, float *act, float
  * (below) runs trainer.train on it; sac_read_batch_device copies it to the host only if somebody looks at it.
  * A token stays valid until (at least) 16 more batches have been drawn (then the calls fail with "expired").
  * Read-ahead: called again and again with nothing in between that touches the generator or the buffer -- the loop above --
- * the call draws and gathers up to eight batches in its two launches and the following calls hand them out.  Every entry
+ * the call draws and gathers up to sixteen batches in its two launches and the following calls hand them out.  Every entry
  * point that reads or changes the generator's state, the buffer's rows or its size (add, seed / get / set state, the
  * other draws, sac_train_loop) first takes the speculation back: the generator's state saved in front of the chunk is
  * restored and advanced by the batches actually handed out.  The index stream is NumPy's, bit for bit, under any

@@ -792,9 +792,9 @@ static int wait_slot_free(sac_buffer *b, int slot) {
     if (b->multi_stream) {
         SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
     } else if (b->free_waited_seq < b->slot_seq[slot]) {
-        const int64_t m = b->slot_seq[slot] | 7;
-        const int idx = (int)((m >> 3) & 3);
-        if (b->free4_seq[idx] == m) {                   // the usual case: recorded ~24 steps ago, long fired
+        const int64_t m = b->slot_seq[slot] | 15;
+        const int idx = (int)((m >> 4) & 3);
+        if (b->free4_seq[idx] == m) {                   // the usual case: recorded ~48 steps ago, long fired
             SAC_HIP(hipStreamWaitEvent(b->stream, b->free4[idx], 0));
             b->free_waited_seq = m;
         } else {                                        // no event at or behind that step yet: record one now
@@ -820,11 +820,11 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
         *token = n;
         return 0;
     }
-    // how many batches this call draws: 1 until the caller has asked twice in a row with nothing in between, then 2, 4, 8
+    // how many batches this call draws: 1 until the caller has asked twice in a row with nothing in between, then 2, 4, 8, 16
     // (never across the end of the ring: the chunk's slots and indices are contiguous)
     int k = 1;
     if (b->ra_enabled && !b->multi_stream) {
-        k = b->ra_streak >= 8 ? 8 : (b->ra_streak >= 4 ? 4 : (b->ra_streak >= 2 ? 2 : 1));
+        k = b->ra_streak >= 16 ? 16 : (b->ra_streak >= 8 ? 8 : (b->ra_streak >= 4 ? 4 : (b->ra_streak >= 2 ? 2 : 1)));
         if (k > sac_buffer::RA_MAX) k = sac_buffer::RA_MAX;
         if (k > sac_buffer::NRING - slot) k = sac_buffer::NRING - slot;
     }

@@ -118,16 +118,16 @@ struct sac_buffer {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // device-resident batches of the stepwise interface (sac_random_batch_device): a ring of NRING slots; batch
     // number n lives in slot n % NRING until batch n + NRING is drawn
-    static constexpr int NRING = 32;                 // (a token stays valid until 16 more batches have been DRAWN: 32 - RA_MAX - 8)
+    static constexpr int NRING = 64;                 // (a token stays valid until at least NRING - RA_MAX = 48 more batches have been drawn)
     float *d_ring = nullptr; int64_t *d_ring_idx = nullptr;
     sac::SlotLayout ring_layout{};
     int64_t ring_next = 0;                           // number of batches drawn so far
     int64_t ring_token[NRING];                       // batch number held by each slot (-1: none)
     hipEvent_t ring_ready[NRING] = {}, ring_free[NRING] = {};
     bool ring_in_use[NRING] = {};                    // a step was launched on the slot and nobody has waited for it since
-    // "the trainer is done with this slot" is signalled by ONE event per eight steps (two runtime calls per step was a
-    // fifth of the stepwise interface's host time): step k (launch sequence) leaves its number in the slot, every eighth
-    // step records free4[(k >> 3) & 3]; a draw that reuses a slot waits for the oldest event recorded at or behind the
+    // "the trainer is done with this slot" is signalled by ONE event per sixteen steps (two runtime calls per step was a
+    // fifth of the stepwise interface's host time): step k (launch sequence) leaves its number in the slot, every sixteenth
+    // step records free4[(k >> 4) & 3] (four events cover the ring of 64); a draw that reuses a slot waits for the oldest event recorded at or behind the
     // slot's step (the per-slot event ring_free[] is the fall-back when no such event exists)
     hipEvent_t free4[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t free4_seq[4] = {-1, -1, -1, -1};
@@ -139,7 +139,7 @@ struct sac_buffer {
     // changes the generator, the buffer's rows or its size first ROLLS the speculation BACK: the generator's state saved
     // in front of the chunk is restored and advanced by the batches that were handed out (one small draw), so the index
     // stream stays NumPy's, bit for bit, whatever the caller interleaves.
-    static constexpr int RA_MAX = 8;
+    static constexpr int RA_MAX = 16;
     int64_t ra_ahead = 0;                            // batches drawn + gathered beyond ring_next
     int ra_chunk = 0, ra_batch = 0;                  // size of the chunk they belong to; the batch size it was drawn for
     int ra_streak = 0;                               // consecutive random_batch_device calls with nothing in between

@@ -2446,7 +2446,7 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
         const int64_t k = b->step_seq++;
         b->slot_seq[slot] = k;
         if (b->multi_stream) SAC_HIP(hipEventRecord(b->ring_free[slot], s));
-        else if ((k & 7) == 7) { SAC_HIP(hipEventRecord(b->free4[(k >> 3) & 3], s)); b->free4_seq[(k >> 3) & 3] = k; }   // (one per EIGHT steps: 4 events cover the ring of 32)
+        else if ((k & 15) == 15) { SAC_HIP(hipEventRecord(b->free4[(k >> 4) & 3], s)); b->free4_seq[(k >> 4) & 3] = k; }   // (one per SIXTEEN steps: 4 events cover the ring of 64)
         b->ring_in_use[slot] = true;
     }
     t->mirror_valid = false;

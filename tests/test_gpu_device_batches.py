@@ -76,7 +76,7 @@ def test_expired_device_batch_is_refused_not_wrong():
     buf = filled(500, O, A, 4)
     buf.seed(1)
     old = buf.random_batch(B)
-    keep = [buf.random_batch(B) for _ in range(40)]         # the ring holds 32 batches (some of them drawn ahead)
+    keep = [buf.random_batch(B) for _ in range(80)]         # the ring holds 64 batches (some of them drawn ahead)
     with pytest.raises(RuntimeError, match="expired"):
         old["observations"]
     with pytest.raises(RuntimeError, match="expired"):
@@ -91,7 +91,7 @@ def test_expired_device_batch_is_refused_not_wrong():
 
 
 def test_read_ahead_keeps_numpys_stream_and_the_buffers_rows_under_any_interleaving():
-    """random_batch draws and gathers up to eight batches ahead once it is called repeatedly (sac_random_batch_device);
+    """random_batch draws and gathers up to sixteen batches ahead once it is called repeatedly (sac_random_batch_device);
     whatever else the caller does in between -- inserts, other batch sizes, reading or setting the generator, host batches,
     index draws, a fused loop -- the indices stay NumPy's and the rows the buffer's at the time of the call."""
     O, A, cap = 9, 3, 20000
