@@ -41,6 +41,16 @@ def test_plain_python_launches_its_own_ranks_and_prints_one_line():
     assert d["elapsed_max_s"] >= steps * ms * 2 * 1e-3
     assert abs(d["value"] - 2 * steps / d["elapsed_max_s"]) <= 0.01 * d["value"]
     assert abs(d["ms_per_step"] - d["elapsed_max_s"] / steps * 1e3) < 1e-3
+    # the ranks of one node line up through shared memory (parallel.NodeBarrier)
+    assert d["ranks_barrier"].startswith("shared memory")
+
+
+def test_the_process_groups_barrier_is_the_fall_back():
+    p = run_bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1",
+                  env_extra=dict(SAC_BENCH_NODE_BARRIER="0"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    assert d["n_gpus"] == 2 and d["ranks_barrier"] == "torch.distributed barrier (gloo)"
 
 
 def test_a_failing_rank_makes_the_launcher_fail():
