@@ -1434,13 +1434,21 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
         // becomes a branch whose merge point needs the data, i.e. a vmcnt(0) right behind the load.
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         auto chunk_of = [&](int sq) { const int m = (sq < s1 - 1) ? sq : s1 - 1; return m > 0 ? m : 0; };
+        // k tiles of this strip that lie inside the layer (a first layer of 80 input columns has a second strip with ONE):
+        // a padding tile re-reads the last valid one -- lines that are in flight anyway -- instead of streaming 16 KB of
+        // zero (or foreign) rows; its products are never used (tile_ok below)
+        int nv = (J.ldp - k0) >> 4;
+        nv = nv > 4 ? 4 : (nv < 1 ? 1 : nv);
+        size_t toff[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) toff[t] = (size_t)(t < nv ? t : nv - 1) * tile_floats;
         f32x4 a[4], b[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int cq = chunk_of(s0 + u);
             a[u] = ld4(yp + 256 * cq);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + t * tile_floats + 256 * cq);
+            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
         }
         f32x4 p4 = {0.f, 0.f, 0.f, 0.f}, m4 = p4, v4 = p4;
         if (own_valid) {
@@ -1487,7 +1495,7 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
                     const int cq = chunk_of(sI + 4 + u);
                     a[u] = ld4(yp + 256 * cq);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + t * tile_floats + 256 * cq);
+                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
                 }
             }
         }
