@@ -1,5 +1,6 @@
-"""GPU: size-independent properties of the hot path at BASELINE.json's full size -- Lift obs 42 / act 7, batch 256, a FULL
-1e6-slot replay buffer -- where the torch oracle would take minutes.  Each property pins a different part of
+"""GPU: size-independent properties of the hot path at BASELINE.json's full sizes -- configs[1] Lift obs 42 / act 7 batch 256
+(the fused step), configs[2] Door 46 / 7 batch 1024 (the four-launch step, column split 1), configs[3] TwoArmLift 89 / 14
+batch 256 -- each on a FULL 1e6-slot replay buffer, where the torch oracle would take minutes.  Each property pins a different part of
 `random_batch -> train` (reference loop: /root/reference/util/rlkit_custom.py:233-240) against something computable on
 the host from the synthetic transitions alone:
 
@@ -21,6 +22,8 @@ pytestmark = pytest.mark.gpu
 
 O, A, B, N = 42, 7, 256, 1_000_000
 D = {n: i for i, n in enumerate(DIAG_NAMES)}
+SHAPES = {"Lift-256": (42, 7, 256), "Door-1024": (46, 7, 1024), "TwoArmLift-256": (89, 14, 256)}
+_cache = {}
 
 
 @pytest.fixture(scope="module")
@@ -28,23 +31,34 @@ def transitions():
     return synth_transitions(N, O, A, seed=77, term_frac=0.02)
 
 
+@pytest.fixture(params=list(SHAPES))
+def shaped(request):
+    """(obs_dim, act_dim, batch, transitions) of a BASELINE configuration; one set of transitions alive at a time."""
+    o, a, b = SHAPES[request.param]
+    if _cache.get("key") != (o, a):
+        _cache.clear()
+        _cache.update(key=(o, a), data=synth_transitions(N, o, a, seed=77, term_frac=0.02))
+    return o, a, b, _cache["data"]
+
+
 def _full_buffer(transitions):
     from robosuite_benchmark_amd import EnvReplayBuffer
     obs, act, rew, term, nobs = transitions
-    buf = EnvReplayBuffer(N, obs_dim=O, action_dim=A)
+    buf = EnvReplayBuffer(N, obs_dim=obs.shape[1], action_dim=act.shape[1])
     buf.add_block(obs, act, rew, nobs, term)
     assert buf.num_steps_can_sample() == N
     return buf
 
 
-def test_discount_zero_targets_are_the_sampled_rewards(transitions):
+def test_discount_zero_targets_are_the_sampled_rewards(shaped):
+    O, A, B, transitions = shaped
     rew = transitions[2].reshape(-1).astype(np.float64)
     scale, steps = 3.0, 40
     _, hip = make_pair(O, A, B, seed=5, noise_seed=2, discount=0.0, reward_scale=scale)
     buf = _full_buffer(transitions)
     buf.seed(1234)
     hip.train_loop(buf, steps, batch_size=B)
-    assert hip.is_fused()
+    assert hip.is_fused() == (B <= 256)
     trace = hip.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
     rs = np.random.RandomState(1234)                       # the generator the reference seeds (scripts/train.py:112)
     for k in range(steps):
@@ -75,7 +89,8 @@ def test_zero_learning_rates_leave_the_networks_bit_identical(transitions):
     assert first[D["QF1 Loss"]] != last[D["QF1 Loss"]]
 
 
-def test_tau_one_makes_the_targets_the_critics_after_every_step(transitions):
+def test_tau_one_makes_the_targets_the_critics_after_every_step(shaped):
+    O, A, B, transitions = shaped
     _, hip = make_pair(O, A, B, seed=7, noise_seed=4, soft_target_tau=1.0, target_update_period=1)
     buf = _full_buffer(transitions)
     buf.seed(10)
