@@ -54,7 +54,9 @@ def _same(sa, sb):
                                          (86, 14, 256, 12), (89, 14, 256, 12), (64, 4, 128, 12), (50, 4, 100, 12),
                                          (10, 3, 16, 25), (112, 16, 48, 8), (1, 1, 17, 8), (60, 7, 250, 8),
                                          # wide first layers (obs_dim > 112: a refilling ring instead of a held one): Wipe
-                                         (379, 6, 256, 10), (379, 7, 128, 6), (130, 5, 64, 8), (113, 7, 48, 6), (496, 3, 32, 4)])
+                                         (379, 6, 256, 10), (379, 7, 128, 6), (130, 5, 64, 8), (113, 7, 48, 6), (496, 3, 32, 4),
+                                         # ... with a two-tile head (2A > 16) and at the 128-column boundary of the split
+                                         (150, 12, 64, 6), (300, 14, 256, 5), (128, 9, 80, 5), (112, 8, 96, 5)])
 def test_fused_step_equals_four_launch_step_bitwise(O, A, B, steps):
     fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9)
     assert fused.is_fused() and not plain.is_fused()
