@@ -128,8 +128,9 @@ struct DwLayer {
     float *TP, *Tbias;             // Polyak target (forward copy / bias) or null
     int N, K, ldp, ldt, nk, job0, xt_from_slot;
     float lr;
+    int k_base, pad_;              // first column of this entry's strips (a first layer's partial last strip is an entry of its own)
 };
-constexpr int NDW = 9;
+constexpr int NDW = 12;           // 3 nets x 3 layers + the tail strips of the first layers (see build_table)
 struct DwTable {                   // L: device array, read with scalar loads
     const DwLayer *L;
     int job0[NDW];
@@ -1412,7 +1413,7 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
         STAMP(4, 3);
 #endif
         const int jj = jb - J.job0;
-        const int n0 = 16 * (jj / J.nk), k0 = 64 * (jj % J.nk);
+        const int n0 = 16 * (jj / J.nk), k0 = J.k_base + 64 * (jj % J.nk);
         // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
         const int k_own = k0 + 16 * wave + r;
         const bool own_valid = k_own < J.K;
@@ -2132,9 +2133,17 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         int job = 0, nl = 0;
         const size_t base = hl.size();
         for (int li = 0; li < NDW; ++li) T.job0[li] = 1 << 30;
-        auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr) {
+        // part 0: the layer's full 64-column strips (all of them unless the layer has a tail); part 1: the TAIL -- the partial
+        // last strip of a first layer with more than one strip (80 input columns: one valid tile of four; the padding tiles
+        // re-read the valid ones).  Tails come last in the table: the launch has more jobs than CUs on those shapes, the
+        // jobs at the end of the table are the ones that share a CU with an earlier job, and a tail job streams 32-64 KB
+        // where a full one streams 80.
+        auto add_layer = [&](int netid, int l, const float *dYT, const float *XT, int from_slot, float lr, int part) {
             Net &n = t->net[netid];
             const Layer &L = n.L[l];
+            const int nk_all = (L.Kp + 63) / 64;
+            const bool has_tail = (l == 0) && (L.Kp % 64 != 0) && nk_all > 1;
+            if (part == 1 && !has_tail) return;
             T.job0[nl++] = job;
             hl.emplace_back();
             DwLayer &J = hl.back();
@@ -2149,7 +2158,8 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
                 J.Tbias = t->net[tgt].P + L.offB;
             }
             J.ldp = L.Kp; J.ldt = L.Np; J.N = L.N; J.K = L.K; J.lr = lr;
-            J.nk = (L.Kp + 63) / 64;
+            J.nk = (part == 1) ? 1 : (has_tail ? nk_all - 1 : nk_all);
+            J.k_base = (part == 1) ? 64 * (nk_all - 1) : 0; J.pad_ = 0;
             J.job0 = job;
             job += (L.Np / 16) * J.nk;
         };
@@ -2157,9 +2167,10 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         const float *dY0[3] = {d.dPH1T, d.dQH1T, d.dQH1T + (size_t)H * B};
         const float *dY2[3] = {d.dheadT, d.dq16T, d.dq16T + (size_t)16 * B}, *X2[3] = {d.PH2T, d.QH2T, d.QH2T + (size_t)H * B};
         const float lrs[3] = {cfg->policy_lr, cfg->qf_lr, cfg->qf_lr};
-        for (int n : nets) add_layer(n, 1, dY1[n], X1[n], 0, lrs[n]);
-        for (int n : nets) add_layer(n, 0, dY0[n], nullptr, 1, lrs[n]);
-        for (int n : nets) add_layer(n, 2, dY2[n], X2[n], 0, lrs[n]);
+        for (int n : nets) add_layer(n, 1, dY1[n], X1[n], 0, lrs[n], 0);
+        for (int n : nets) add_layer(n, 0, dY0[n], nullptr, 1, lrs[n], 0);
+        for (int n : nets) add_layer(n, 2, dY2[n], X2[n], 0, lrs[n], 0);
+        for (int n : nets) add_layer(n, 0, dY0[n], nullptr, 1, lrs[n], 1);
         T.njobs = job;
         T.L = t->d_dwl + base;
         T.abort = nullptr;
