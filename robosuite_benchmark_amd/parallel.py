@@ -47,7 +47,7 @@ class NodeBarrier:
     spans nodes, the caller keeps using dist.barrier()."""
     LINE = 8                                   # int64 per rank line (64 B)
 
-    def __init__(self, dist, rank, world, timeout_s=120.0):
+    def __init__(self, dist, rank, world, timeout_s=900.0):
         import mmap
         import numpy as np
         self.rank, self.world, self.timeout_s, self.epoch = rank, world, timeout_s, 0
