@@ -1346,7 +1346,10 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
         sh[wave * 32 + 24] = lsum;
     }
     lds_barrier();
-    float *const dlast = (sa.pad2 & 2u) ? d.diag_last : d.diag_dev;
+    // TD3's vector is filled by two launches, its policy half on policy steps only: every launch updates the DEVICE copy
+    // (which so always holds the most recent value of each entry), and a launch whose caller reads the diagnostics
+    // (sa.pad2 bit 1: the last step of a loop, single steps) copies the whole vector to the mapped host buffer at its end
+    float *const dlast = d.diag_dev;
     auto put = [&](int di, float v) {
         dlast[di] = v;
         if (loop_pos == 0) d.diag_first[di] = v;
@@ -1373,6 +1376,10 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
         double s = 0;
         for (int w = 0; w < 4; ++w) s += sh[w * 32 + 24];
         put(SAC_D_POLICY_LOSS, (float)(-s / B));
+    }
+    if (sa.pad2 & 2u) {
+        __syncthreads();
+        if (threadIdx.x < SAC_DIAG_N) d.diag_last[threadIdx.x] = ld_sc1(d.diag_dev + threadIdx.x);
     }
 }
 
@@ -1847,9 +1854,9 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
     const double tq = (double)(t->adam_t + 1), tp = (double)(t->adam_t_pi + 1);
     StepArg sq{t->n_train_steps_total, t->adam_t + 1, j, 1, 1.0 - std::pow(0.9, tq), std::sqrt(1.0 - std::pow(0.999, tq))};
     StepArg sp{t->n_train_steps_total, t->adam_t_pi + 1, j, 2, 1.0 - std::pow(0.9, tp), std::sqrt(1.0 - std::pow(0.999, tp))};
-    // (TD3's diagnostics vector is filled by two launches and its policy half only on policy steps: every step goes to the
-    //  host buffer, so "last" keeps meaning the most recent value of each entry)
-    sq.pad2 = sp.pad2 = 2u;
+    // (the diagnostics -- and the flat gradient copies of sac_debug_fetch -- go out only on the steps whose caller reads
+    //  them, like the SAC step's; td3_diagnostics keeps "last" the most recent value of each entry across launches)
+    sq.pad2 = sp.pad2 = t->publish_diag ? 2u : 0u;
     hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
     hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
     hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
