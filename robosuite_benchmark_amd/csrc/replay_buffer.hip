@@ -499,7 +499,7 @@ static int add_impl(sac_buffer *b, int64_t n, const Src *obs, const Src *act, co
 extern "C" {
 
 const char *sac_last_error(void) { return sac::last_error(); }
-const char *sac_version(void) { return "sac_hip 0.1 (gfx950)"; }
+const char *sac_version(void) { return "sac_hip 0.2 (gfx950)"; }
 
 int sac_device_count(void) {
     int n = 0;
