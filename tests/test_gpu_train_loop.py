@@ -87,6 +87,26 @@ def test_loop_lengths_do_not_disturb_each_other():
         assert np.array_equal(sa["params"][k], sb["params"][k]), k
 
 
+def test_loops_around_the_length_of_the_slot_ring():
+    """Calls of up to 512 steps never reuse a slot of the loop's ring (no chunk-done events at all); longer ones wrap it and
+    wait for the chunks that still own the slots.  Both sides of that boundary against the stepwise interface."""
+    O, A, B, n = 42, 7, 64, 20000
+    bufs = [filled_buffer(n, O, A, 8), filled_buffer(n, O, A, 8)]
+    for b in bufs:
+        b.seed(11)
+    _, fused = make_pair(O, A, B, seed=4, noise_seed=3)
+    _, stepw = make_pair(O, A, B, seed=4, noise_seed=3)
+    for steps in (512, 513, 1100, 511):
+        fused.train_loop(bufs[0], steps, batch_size=B)
+        for _ in range(steps):
+            stepw.train(bufs[1].random_batch(B))
+        sa, sb = fused.state_dict(), stepw.state_dict()
+        for k in sa["params"]:
+            assert np.array_equal(sa["params"][k], sb["params"][k]), (steps, k)
+        ka, kb = bufs[0].rng_state(), bufs[1].rng_state()
+        assert ka[1] == kb[1] and np.array_equal(ka[0], kb[0]), steps
+
+
 def test_loop_behind_work_in_flight_on_the_buffers_stream():
     """The first chunk of a loop is drawn and gathered on the TRAINER's stream; an ingest whose copies are still in flight
     and a device-resident random_batch nobody consumed live on the BUFFER's stream.  The loop must see the ingested rows
