@@ -152,3 +152,29 @@ def test_read_ahead_keeps_numpys_stream_and_the_buffers_rows_under_any_interleav
     key, pos = buf.rng_state()
     st = ref.get_state()
     assert pos == st[2] and np.array_equal(key, st[1])
+
+
+def test_two_trainers_take_turns_on_one_buffers_device_batches():
+    """One buffer, two trainers (two step streams): after a stretch with ONE trainer -- the buffer reads ahead, one
+    slot-release event per sixteen steps -- a second trainer joins and the buffer switches to one event per step and one
+    batch per draw.  Batches drawn ahead before the switch are still handed out and waited for correctly.  Everything
+    against the same schedule on host batches, bitwise."""
+    O, A, B, n = 42, 7, 64, 8000
+    runs = []
+    for lazy in (True, False):
+        buf = filled(n, O, A, 9, lazy_batches=lazy)
+        buf.seed(21)
+        _, t1 = make_pair(O, A, B, seed=5, noise_seed=1)
+        _, t2 = make_pair(O, A, B, seed=6, noise_seed=2)
+        for _ in range(40):                                  # trainer 1 alone: read-ahead chunks of up to 16
+            t1.train(buf.random_batch(B))
+        for i in range(120):                                 # both, in turns and in pairs
+            (t1 if i % 3 else t2).train(buf.random_batch(B))
+        for _ in range(50):                                  # trainer 2 alone again
+            t2.train(buf.random_batch(B))
+        runs.append((t1.state_dict(), t2.state_dict(), buf.rng_state()))
+    (a1, a2, ra), (b1, b2, rb) = runs
+    for x, y in ((a1, b1), (a2, b2)):
+        for k in x["params"]:
+            assert np.array_equal(x["params"][k], y["params"][k]), k
+    assert ra[1] == rb[1] and np.array_equal(ra[0], rb[0])
