@@ -2466,8 +2466,14 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     const int rc_step = launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr);
     t->publish_diag = true;
     if (rc_step) return -1;
-    {   // (see sac_buffer::free4: one "done with the slots so far" event per four steps)
-        if (b->step_stream && b->step_stream != s) b->multi_stream = true;
+    {   // (see sac_buffer::free4: one "done with the slots so far" event per sixteen steps)
+        if (b->step_stream && b->step_stream != s && !b->multi_stream) {
+            // a second trainer: one event per step from here on.  The first trainer's steps in flight were covered by the
+            // per-sixteen-steps events only: the buffer's stream waits for all of them once, here
+            SAC_HIP(hipEventRecord(b->free4[0], b->step_stream));
+            SAC_HIP(hipStreamWaitEvent(b->stream, b->free4[0], 0));
+            b->multi_stream = true;
+        }
         b->step_stream = s;
         const int64_t k = b->step_seq++;
         b->slot_seq[slot] = k;
