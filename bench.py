@@ -95,11 +95,16 @@ def fill_buffer(buf, n, O, A, seed):
     buf.ingest_wait()                                                   # (inserts are asynchronous)
 
 
+B_INIT = 0.1
+
+
 def build_replica(task, O, A, B, n_buf, seed, device):
     from robosuite_benchmark_amd import EnvReplayBuffer, FlattenMlp, SACTrainer, TanhGaussianPolicy
     rs = np.random.RandomState(seed)
-    pol = TanhGaussianPolicy([H, H], O, A, rs=rs)
-    qs = [FlattenMlp([H, H], 1, O + A, rs=rs) for _ in range(4)]
+    # (initial hidden bias stated explicitly -- rlkit's Mlp default at the commit the reference pins; "parity unpinned",
+    #  DESIGN.md section 2 -- so that the final losses recorded per round stay comparable whatever the holders default to)
+    pol = TanhGaussianPolicy([H, H], O, A, rs=rs, b_init_value=B_INIT)
+    qs = [FlattenMlp([H, H], 1, O + A, rs=rs, b_init_value=B_INIT) for _ in range(4)]
     # trainer_kwargs of every shipped variant.json (RUN17/variant.json:52-58)
     trainer = SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], discount=0.99,
                          reward_scale=1.0, policy_lr=1e-3, qf_lr=5e-4, soft_target_tau=0.005,
@@ -183,8 +188,8 @@ def cpu_baseline(O, A, B, n_host=1_000_000, budget_s=45.0):
 def build_td3_replica(O, A, B, n_buf, seed, device=0):
     from robosuite_benchmark_amd import EnvReplayBuffer, FlattenMlp, TanhMlpPolicy, TD3Trainer
     rs = np.random.RandomState(seed)
-    pols = [TanhMlpPolicy([H, H], A, O, rs=rs) for _ in range(2)]
-    qs = [FlattenMlp([H, H], 1, O + A, rs=rs) for _ in range(4)]
+    pols = [TanhMlpPolicy([H, H], A, O, rs=rs, b_init_value=B_INIT) for _ in range(2)]
+    qs = [FlattenMlp([H, H], 1, O + A, rs=rs, b_init_value=B_INIT) for _ in range(4)]
     tr = TD3Trainer(policy=pols[0], qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], target_policy=pols[1],
                     target_policy_noise=0.2, discount=0.99, reward_scale=1.0, policy_learning_rate=1e-3,
                     qf_learning_rate=5e-4, policy_and_target_update_period=2, tau=0.005, batch_size=B,
@@ -315,33 +320,59 @@ def _free_port():
 def launch_ranks(n, argv):
     """Parent of a self-launched N-rank job.  Nothing here touches a GPU API (no torch.cuda, no HIP): the children
     are started first and this process only waits, so no process that has initialised the GPU is ever re-executed.
-    Rank 0's stdout carries the JSON line; the other ranks' stdout goes to stderr.  Exit code != 0 if any rank fails."""
+    Rank 0's stdout carries the JSON line; every rank's stderr is kept (a temporary file per rank) and shown when the
+    job fails.  ALL children are polled: the moment any rank exits non-zero the others -- which would otherwise sit in a
+    rendezvous or barrier until its timeout, 15-30 minutes -- are ended (exactly the PIDs started here) and the parent
+    exits non-zero naming the culprit."""
+    import tempfile
     env0 = dict(os.environ)
     env0.setdefault("MASTER_ADDR", "127.0.0.1")
     env0["MASTER_PORT"] = str(_free_port())
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    procs = []
+    procs, errs, outs = [], [], []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        errs.append(tempfile.TemporaryFile(mode="w+", prefix=f"bench_rank{r}_err_"))
+        outs.append(tempfile.TemporaryFile(mode="w+", prefix=f"bench_rank{r}_out_"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:        # a rank that outlives rank 0 by minutes is stuck: end exactly that PID
-            p.kill()
-            rcs.append(p.wait())
-    if any(rc != 0 for rc in rcs):
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+                                      stdout=outs[r], stderr=errs[r], text=True))
+    rcs, failed = [None] * n, None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            time.sleep(0.5)                       # (ranks that die of the same cause get to say so themselves)
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    p.kill()
+                rcs[r] = p.wait()
+            break
+        time.sleep(0.02)
+
+    def text_of(f):
+        f.seek(0)
+        return f.read()
+    out0 = text_of(outs[0])
+    for r in range(1, n):                         # the other ranks' stdout is not the result: pass it on as diagnostics
+        t = text_of(outs[r])
+        if t:
+            sys.stderr.write(t)
+    if failed is not None:
+        sys.stderr.write(f"bench.py: rank {failed} failed first; rank exit codes {rcs}\n")
+        for r in range(n):
+            t = text_of(errs[r])
+            if t.strip():
+                sys.stderr.write(f"---- rank {r} stderr (last lines) ----\n" + "\n".join(t.splitlines()[-25:]) + "\n")
         if out0:
             sys.stderr.write(out0)
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         raise SystemExit(1)
+    for r in range(n):
+        t = text_of(errs[r])
+        if t:
+            sys.stderr.write(t)
     lines = [l for l in (out0 or "").splitlines() if l.strip().startswith("{")]
     if len(lines) != 1:
         sys.stderr.write(f"bench.py: expected one JSON line from rank 0, got {len(lines)}\n{out0}\n")
@@ -383,6 +414,11 @@ def main():
                     help="no GPU at all: ranks sleep instead of training (tests of the launcher and the N>1 plumbing; "
                          "use with --backend gloo)")
     ap.add_argument("--dry-run-ms-per-step", type=float, default=1.0)
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1,
+                    help="--dry-run only (launcher tests): this rank exits with code 3 before the rendezvous")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1: still initialise the process group (world size 1) so that the N>1 branch -- RCCL set-up, "
+                         "barriers, max-over-ranks, the result all-gather -- runs on a one-GPU box")
     ap.add_argument("--profile-steps", type=int, default=500)
     ap.add_argument("--agent", type=str, default="SAC", choices=["SAC", "TD3"],
                     help="TD3: the SURVEY 8f row on the same workload shape (N=1, its own JSON line); default SAC = the headline metric")
@@ -404,8 +440,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
+    if args.dry_run and rank == args.dry_run_fail_rank:
+        sys.stderr.write("bench.py: rank %d exits on purpose (--dry-run-fail-rank)\n" % rank)
+        raise SystemExit(3)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist = parallel.init_process_group(args.backend, local_rank)   # nccl == RCCL on ROCm
     if args.single_device:
         local_rank = 0
@@ -588,7 +630,11 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     if world == 1 and not args.no_stepwise:
         # the reference's unmodified loop body (random_batch -> train) through the Python duck types, batches
         # staying on the device (DeviceBatch): extra data point, never `value`
+        # Sampling: the construction default of the drop-in -- the buffer bound to np.random itself (train.py:112), the
+        # process-wide stream right after every call, no hand-over.
         n_sw = min(args.steps, 2000)
+        np.random.seed(17)
+        buf.bind_numpy_global_stream()
         for _ in range(50):
             trainer.train(buf.random_batch(B))
         trainer._lib.sac_sync(trainer._h)
@@ -597,7 +643,14 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
             trainer.train(buf.random_batch(B))
         trainer._lib.sac_sync(trainer._h)
         out["stepwise_interface"] = dict(value=round(n_sw / (time.perf_counter() - t0), 2), unit="grad-steps/s", steps=n_sw,
+                                         sampling="np.random global stream (construction default; state words bound: %s)" % buf._bound,
                                          note="replay_buffer.random_batch(B); trainer.train(batch) per step from Python")
+        ref = np.random.RandomState(17)
+        for _ in range(50 + n_sw):
+            ref.randint(0, buf.num_steps_can_sample(), B)
+        out["stepwise_interface"]["np_random_is_where_rlkit_would_leave_it"] = bool(
+            np.array_equal(np.random.get_state()[1], ref.get_state()[1]) and np.random.get_state()[2] == ref.get_state()[2])
+        buf.seed(17)
     if world == 1:
         # asynchronous ingest: one epoch's 2 500 exploration rows; host-blocking time of the
         # insert call vs the time until the rows have landed in HBM

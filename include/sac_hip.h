@@ -79,6 +79,16 @@ int sac_buffer_set_cursor(sac_buffer_t *buf, int64_t top, int64_t size);
 int sac_rng_seed(sac_buffer_t *buf, uint32_t seed);
 int sac_rng_get_state(sac_buffer_t *buf, uint32_t key[624], int32_t *pos);
 int sac_rng_set_state(sac_buffer_t *buf, const uint32_t key[624], int32_t pos);
+/* Bind the generator to a HOST-resident MT19937 state: key[624] + *pos are the words of np.random's own state struct
+ * (numpy.random.MT19937().ctypes.state_address: {uint32_t key[624]; int pos;}), so the buffer samples THE process-wide
+ * stream the reference seeds at /root/reference/scripts/train.py:112 and rlkit's random_batch consumes -- by default,
+ * with no per-call state transfer: every device draw is mirrored on those host words (a few ns per index), which are
+ * therefore right when the call returns, and a change anybody else made to them (np.random.seed, np.random.set_state, a
+ * host consumer such as an env reset) is noticed in front of the next draw and adopted.  The read-ahead of
+ * sac_random_batch_device survives (the speculation is only dropped when the host words were changed from outside).
+ * While bound, sac_rng_seed / sac_rng_set_state write through to the host words and sac_rng_get_state reads them.
+ * key == NULL unbinds (the generator keeps its current state, privately).  The memory must outlive the binding. */
+int sac_rng_bind_host(sac_buffer_t *buf, uint32_t *key, int32_t *pos);
 
 /* np.random.randint(0, size, batch) drawn n_batches times on the device, bit-exact with NumPy
  * including rejected draws and the generator state afterwards.  idx_out (host, n_batches*batch

@@ -73,6 +73,7 @@ SYMBOLS = {
     "sac_rng_seed": (C.c_int, [_P, C.c_uint32]),
     "sac_rng_get_state": (C.c_int, [_P, _P, C.POINTER(C.c_int32)]),
     "sac_rng_set_state": (C.c_int, [_P, _P, C.c_int32]),
+    "sac_rng_bind_host": (C.c_int, [_P, _P, _P]),
     "sac_sample_indices": (C.c_int, [_P, C.c_int, C.c_int64, _P]),
     "sac_random_batch": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "sac_random_batch_device": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),

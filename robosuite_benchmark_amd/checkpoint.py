@@ -46,18 +46,36 @@ def _fsync_dir(path):
         os.close(fd)
 
 
+def _generations(dirname):
+    return sorted(int(d[4:]) for d in os.listdir(dirname) if d.startswith("gen-") and d[4:].isdigit())
+
+
 def current_dir(dirname):
-    """The directory holding the newest COMPLETE save under `dirname`, or None.  Saves are generations
-    `<dirname>/gen-<n>/`; `<dirname>/latest` names the newest complete one and is replaced atomically, last."""
+    """The directory holding the newest COMPLETE save under `dirname`, or None when there is no save at all.  Saves are
+    generations `<dirname>/gen-<n>/`; `<dirname>/latest` names the newest complete one and is replaced atomically, last.
+    A `latest` that names a generation without a manifest (somebody removed or damaged it) is NOT "no checkpoint" -- a
+    resuming run would silently start from scratch and its first save would delete what is left: the newest other
+    generation that has a manifest is used (load_checkpoint verifies its CRCs), then the flat layout of the first format
+    revision; only if neither exists the dangling pointer is an error."""
+    if not os.path.isdir(dirname):
+        return None
     ptr = os.path.join(dirname, "latest")
+    flat = os.path.exists(os.path.join(dirname, "manifest.json"))
     if os.path.exists(ptr):
         with open(ptr) as f:
             sub = f.read().strip()
         cand = os.path.join(dirname, sub)
         if sub and os.path.exists(os.path.join(cand, "manifest.json")):
             return cand
-        return None
-    if os.path.exists(os.path.join(dirname, "manifest.json")):       # flat layout of the first format revision
+        for g in reversed(_generations(dirname)):
+            alt = os.path.join(dirname, f"gen-{g}")
+            if os.path.exists(os.path.join(alt, "manifest.json")):
+                return alt
+        if flat:
+            return dirname
+        raise FileNotFoundError(f"{dirname}: `latest` names '{sub}', which holds no manifest, and no other complete "
+                                "generation exists -- refusing to treat a damaged checkpoint directory as 'no checkpoint'")
+    if flat:                                                          # flat layout of the first format revision
         return dirname
     return None
 
@@ -74,7 +92,7 @@ def save_checkpoint(dirname, trainer, replay_buffer=None, extra=None):
     os.makedirs(dirname, exist_ok=True)
     if trainer._h is None:
         raise RuntimeError("the trainer owns no device state yet (construct it with batch_size= or train once)")
-    gens = sorted(int(d[4:]) for d in os.listdir(dirname) if d.startswith("gen-") and d[4:].isdigit())
+    gens = _generations(dirname)
     sub = f"gen-{(gens[-1] + 1) if gens else 0}"
     gdir = os.path.join(dirname, sub)
     os.makedirs(gdir)

@@ -6,6 +6,8 @@
 #include "sac_common.h"
 
 #include <cstring>
+#include <mutex>
+#include <unordered_set>
 #include <vector>
 
 namespace sac {
@@ -373,8 +375,112 @@ int readahead_rollback(sac_buffer *b) {
     return 0;
 }
 
+// ---- streams of live trainers -------------------------------------------------------------------------------
+// A buffer remembers the stream its device-batch steps run on (step_stream: slot-release events are recorded there).
+// That stream belongs to a trainer, which may be destroyed, re-created for another batch size or moved to a CU-masked
+// stream while the buffer lives on: before the buffer touches the handle it asks whether the stream still exists.  (A
+// trainer drains its stream before giving it up, so a dead stream has no step in flight: its slots are simply free.)
+static std::mutex g_streams_mu;
+static std::unordered_set<hipStream_t> g_streams;
+void stream_register(hipStream_t s) { std::lock_guard<std::mutex> lk(g_streams_mu); g_streams.insert(s); }
+void stream_unregister(hipStream_t s) { std::lock_guard<std::mutex> lk(g_streams_mu); g_streams.erase(s); }
+bool stream_is_live(hipStream_t s) { std::lock_guard<std::mutex> lk(g_streams_mu); return g_streams.count(s) != 0; }
+
+void forget_dead_step_stream(sac_buffer *b) {
+    if (!b->step_stream || stream_is_live(b->step_stream)) return;
+    b->step_stream = nullptr;
+    b->multi_stream = false;                 // (events of per-step mode recorded on the dead stream have long fired)
+    b->waited_stream = nullptr; b->waited_chunk_token = -1;
+    for (int i = 0; i < sac_buffer::NRING; ++i) b->ring_in_use[i] = false;
+    for (int i = 0; i < 4; ++i) b->free4_seq[i] = -1;
+    b->free_waited_seq = b->step_seq - 1;
+}
+
+// ---- the generator bound to a host-resident state (sac_rng_bind_host) -------------------------------------
+// Sequential MT19937 + masked rejection, the same stream k_mt_randint walks on the device.
+static inline void mt_twist_host(uint32_t *mt) {
+    auto mix = [](uint32_t hi, uint32_t lo, uint32_t far) {
+        const uint32_t y = (hi & 0x80000000u) | (lo & 0x7fffffffu);
+        return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    int i = 0;
+    for (; i < MT_N - MT_M; ++i) mt[i] = mix(mt[i], mt[i + 1], mt[i + MT_M]);
+    for (; i < MT_N - 1; ++i) mt[i] = mix(mt[i], mt[i + 1], mt[i + (MT_M - MT_N)]);
+    mt[MT_N - 1] = mix(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+}
+
+static void mt_skip_accepted(MtState &st, uint32_t rng, uint32_t mask, int64_t count) {
+    int pos = st.pos;
+    while (count > 0) {
+        if (pos >= MT_N) { mt_twist_host(st.mt); pos = 0; }
+        uint32_t y = st.mt[pos++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        count -= ((y & mask) <= rng) ? 1 : 0;
+    }
+    st.pos = pos;
+}
+
+static int upload_rng(sac_buffer *b, const MtState &s) {
+    SAC_HIP(hipMemcpyAsync(b->d_rng, &s, sizeof(MtState), hipMemcpyHostToDevice, b->stream));
+    SAC_HIP(hipStreamSynchronize(b->stream));      // (s may be a local; rare path: only when somebody else moved the stream)
+    return 0;
+}
+
+// the speculative batches nobody asked for are void (the generator is about to be replaced: nothing to restore)
+static void readahead_drop(sac_buffer *b) {
+    b->ra_streak = 0;
+    for (int64_t j = 0; j < b->ra_ahead; ++j) b->ring_token[(b->ring_next + j) % sac_buffer::NRING] = -1;
+    b->ra_ahead = 0;
+}
+
+int host_rng_sync_in(sac_buffer *b) {
+    if (!b->host_key) return 0;
+    const int32_t hp = *b->host_pos;
+    if (hp == b->host_seen.pos && memcmp(b->host_key, b->host_seen.mt, sizeof(uint32_t) * MT_N) == 0) return 0;
+    SAC_REQUIRE(hp >= 0 && hp <= MT_N, "bound host generator holds an invalid position %d", (int)hp);
+    readahead_drop(b);
+    memcpy(b->host_seen.mt, b->host_key, sizeof(uint32_t) * MT_N);
+    b->host_seen.pos = hp;
+    return upload_rng(b, b->host_seen);
+}
+
+// the state `st` as n_batches draws of `batch` indices from a buffer of this size leave it
+void host_rng_skip(const sac_buffer *b, MtState &st, int batch, int64_t n_batches) {
+    if (b->size <= 1) return;                          // (size 1: NumPy consumes no draws)
+    const uint32_t rng = (uint32_t)(b->size - 1);
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    mt_skip_accepted(st, rng, mask, (int64_t)batch * n_batches);
+}
+
+// host_seen mirrors the generator ALWAYS (bound or not: ~5 ns per index, beside a device draw of ~1 us per batch); a bound
+// generator also writes the new state through to the caller's words
+void host_rng_advance(sac_buffer *b, int batch, int64_t n_batches) {
+    host_rng_skip(b, b->host_seen, batch, n_batches);
+    if (b->host_key) {
+        memcpy(b->host_key, b->host_seen.mt, sizeof(uint32_t) * MT_N);
+        *b->host_pos = b->host_seen.pos;
+    }
+}
+
+int host_rng_adopt(sac_buffer *b, const MtState &s) {
+    b->host_seen = s;
+    if (b->host_key) {
+        memcpy(b->host_key, s.mt, sizeof(uint32_t) * MT_N);
+        *b->host_pos = s.pos;
+    }
+    return upload_rng(b, s);
+}
+
 int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offset, int64_t *dst, hipStream_t on) {
-    if (!b->ra_internal && readahead_rollback(b)) return -1;
+    if (!b->ra_internal) {
+        SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
+        if (host_rng_sync_in(b)) return -1;
+        if (readahead_rollback(b)) return -1;
+    }
     hipStream_t q = on ? on : b->stream;
     const int bp = round_up(batch, RB);
     const int64_t count = (int64_t)batch * n_batches, padded = (int64_t)bp * n_batches;
@@ -394,6 +500,7 @@ int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offse
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(256), 0, q, b->d_rng, rng, mask, count, dst, batch, bp);
     SAC_HIP(hipGetLastError());
+    if (!b->ra_internal) host_rng_advance(b, batch, n_batches);      // (behind the launch: the device draws meanwhile)
     return 0;
 }
 
@@ -676,6 +783,8 @@ int sac_buffer_set_cursor(sac_buffer_t *b, int64_t top, int64_t size) {
     return 0;
 }
 
+static int adopt_state(sac_buffer *b, const MtState &s) { return sac::host_rng_adopt(b, s); }
+
 int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_HIP(hipSetDevice(b->device));
@@ -685,18 +794,40 @@ int sac_rng_seed(sac_buffer_t *b, uint32_t seed) {
     s.mt[0] = seed;
     for (int i = 1; i < MT_N; ++i) s.mt[i] = 1812433253u * (s.mt[i - 1] ^ (s.mt[i - 1] >> 30)) + (uint32_t)i;
     s.pos = MT_N;
-    SAC_HIP(hipMemcpyAsync(b->d_rng, &s, sizeof(s), hipMemcpyHostToDevice, b->stream));
-    SAC_HIP(hipStreamSynchronize(b->stream));
-    return 0;
+    return adopt_state(b, s);
+}
+
+int sac_rng_bind_host(sac_buffer_t *b, uint32_t *key, int32_t *pos) {
+    SAC_REQUIRE(b != nullptr && (key == nullptr) == (pos == nullptr), "bad arguments to sac_rng_bind_host");
+    SAC_HIP(hipSetDevice(b->device));
+    if (host_rng_sync_in(b)) return -1;          // (a pending outside change of the old binding is adopted first)
+    if (readahead_rollback(b)) return -1;
+    if (!key) { b->host_key = nullptr; b->host_pos = nullptr; return 0; }
+    SAC_REQUIRE(*pos >= 0 && *pos <= MT_N, "host generator holds an invalid position %d", (int)*pos);
+    b->host_key = key; b->host_pos = pos;
+    memcpy(b->host_seen.mt, key, sizeof(uint32_t) * MT_N);
+    b->host_seen.pos = *pos;
+    return upload_rng(b, b->host_seen);
 }
 
 int sac_rng_get_state(sac_buffer_t *b, uint32_t key[624], int32_t *pos) {
     SAC_REQUIRE(b && key && pos, "bad arguments to sac_rng_get_state");
     SAC_HIP(hipSetDevice(b->device));
-    if (readahead_rollback(b)) return -1;        // (the state a caller sees is the state behind the batches it was GIVEN)
+    if (b->host_key) {       // bound: the host words ARE the state behind the batches handed out (no device round trip,
+        if (host_rng_sync_in(b)) return -1;      // and the read-ahead stays)
+        memcpy(key, b->host_seen.mt, sizeof(uint32_t) * MT_N);
+        *pos = b->host_seen.pos;
+        return 0;
+    }
+    // private stream: the DEVICE generator's own words (behind the batches the caller was GIVEN: the speculation goes
+    // back first) -- and they must be what the host mirror says they are
+    if (readahead_rollback(b)) return -1;
     MtState s;
     SAC_HIP(hipMemcpyAsync(&s, b->d_rng, sizeof(s), hipMemcpyDeviceToHost, b->stream));
     SAC_HIP(hipStreamSynchronize(b->stream));
+    SAC_REQUIRE(s.pos == b->host_seen.pos && memcmp(s.mt, b->host_seen.mt, sizeof(uint32_t) * MT_N) == 0,
+                "internal: the device generator (pos %d) and its host mirror (pos %d) have diverged", (int)s.pos,
+                (int)b->host_seen.pos);
     memcpy(key, s.mt, sizeof(uint32_t) * MT_N);
     *pos = s.pos;
     return 0;
@@ -710,9 +841,7 @@ int sac_rng_set_state(sac_buffer_t *b, const uint32_t key[624], int32_t pos) {
     memset(&s, 0, sizeof(s));
     memcpy(s.mt, key, sizeof(uint32_t) * MT_N);
     s.pos = pos;
-    SAC_HIP(hipMemcpyAsync(b->d_rng, &s, sizeof(s), hipMemcpyHostToDevice, b->stream));
-    SAC_HIP(hipStreamSynchronize(b->stream));
-    return 0;
+    return adopt_state(b, s);
 }
 
 int sac_sample_indices(sac_buffer_t *b, int batch, int64_t n_batches, int64_t *idx_out) {
@@ -757,6 +886,8 @@ static int ensure_ring(sac_buffer *b, int batch) {
     if (b->d_ring && b->ring_layout.Bt == batch) return 0;
     if (readahead_rollback(b)) return -1;
     SAC_HIP(hipStreamSynchronize(b->stream));
+    forget_dead_step_stream(b);
+    if (b->step_stream) SAC_HIP(hipStreamSynchronize(b->step_stream));       // (steps still reading the old ring)
     if (b->d_ring) { SAC_HIP(hipFree(b->d_ring)); SAC_HIP(hipFree(b->d_ring_idx)); b->d_ring = nullptr; b->d_ring_idx = nullptr; }
     b->ring_layout = make_slot_layout(batch, b->O, b->A);
     const size_t nfl = (size_t)b->ring_layout.slot_floats * sac_buffer::NRING;
@@ -772,6 +903,7 @@ static int ensure_ring(sac_buffer *b, int batch) {
     }
     if (const char *e = getenv("SAC_READAHEAD")) b->ra_enabled = atoi(e) != 0;
     b->waited_chunk_token = -1; b->waited_stream = nullptr;
+    b->step_stream = nullptr; b->multi_stream = false;       // (a fresh ring: no step of any trainer is in flight on it)
     for (int i = 0; i < sac_buffer::NRING; ++i) {
         b->ring_token[i] = -1; b->ring_in_use[i] = false;
         b->ring_first[i] = i; b->ring_chunk_token[i] = -1;
@@ -788,6 +920,8 @@ static int ensure_ring(sac_buffer *b, int batch) {
 
 // the slot's previous batch may still be read by a step in flight on a trainer's stream: the buffer's stream waits
 static int wait_slot_free(sac_buffer *b, int slot) {
+    if (!b->ring_in_use[slot]) return 0;
+    forget_dead_step_stream(b);
     if (!b->ring_in_use[slot]) return 0;
     if (b->multi_stream) {
         SAC_HIP(hipStreamWaitEvent(b->stream, b->ring_free[slot], 0));
@@ -811,6 +945,8 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     SAC_REQUIRE(b && batch > 0 && token, "bad arguments to sac_random_batch_device");
     SAC_HIP(hipSetDevice(b->device));
     if (ensure_ring(b, batch)) return -1;
+    SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
+    if (host_rng_sync_in(b)) return -1;      // (bound generator: somebody else moved np.random -> the speculation is void)
     const int64_t n = b->ring_next;
     const int slot = (int)(n % sac_buffer::NRING);
     if (b->ra_ahead > 0) {                   // drawn and gathered ahead by an earlier call: hand it out
@@ -818,6 +954,7 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
         b->ra_streak += 1;
         b->ring_next = n + 1;
         *token = n;
+        host_rng_advance(b, batch, 1);
         return 0;
     }
     // how many batches this call draws: 1 until the caller has asked twice in a row with nothing in between, then 2, 4, 8, 16
@@ -847,6 +984,7 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     b->ra_streak += 1;
     b->ring_next = n + 1;
     *token = n;
+    host_rng_advance(b, batch, 1);           // (the batch HANDED OUT: the host words never run ahead of the caller)
     return 0;
 }
 

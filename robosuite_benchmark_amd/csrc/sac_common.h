@@ -153,6 +153,14 @@ struct sac_buffer {
     int64_t waited_chunk_token = -1;
     hipStream_t step_stream = nullptr;               // the stream the steps are launched on (one trainer per buffer; a second
     bool multi_stream = false;                       // stream switches to one event per step)
+    // host_seen: the generator's state behind the batches HANDED OUT, mirrored on the host -- every draw on the device is
+    // repeated by the same sequential draw here (~5 ns per index).  It is what a fused step that gave up is replayed from
+    // (sac_train_loop), and what binds the generator to a HOST-resident MT19937 state (sac_rng_bind_host: np.random's own
+    // state struct): the new state is written straight into the caller's words, so np.random is right after every
+    // random_batch without a device round trip -- and a change made by anybody else (np.random.seed, a host consumer) is
+    // noticed by comparing those words with host_seen in front of the next draw.
+    uint32_t *host_key = nullptr; int32_t *host_pos = nullptr;
+    sac::MtState host_seen{};
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
 };
 
@@ -173,4 +181,15 @@ int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batc
 // undo the stepwise interface's read-ahead (see sac_buffer::ra_ahead); to be called in front of anything that reads or
 // changes the generator's state, the buffer's rows or its size
 int readahead_rollback(sac_buffer *b);
+// bound generator (sac_rng_bind_host): adopt a host state somebody else changed (in front of a draw) / mirror the draws
+// of n_batches x batch indices on the host state (behind it)
+int host_rng_sync_in(sac_buffer *b);
+void host_rng_advance(sac_buffer *b, int batch, int64_t n_batches);
+void host_rng_skip(const sac_buffer *b, MtState &st, int batch, int64_t n_batches);
+int host_rng_adopt(sac_buffer *b, const MtState &s);      // a new generator state: mirror, bound host words, device
+// streams of live trainers (a buffer remembers the stream its steps run on: it must not outlive the trainer there)
+void stream_register(hipStream_t s);
+void stream_unregister(hipStream_t s);
+bool stream_is_live(hipStream_t s);
+void forget_dead_step_stream(sac_buffer *b);
 }  // namespace sac

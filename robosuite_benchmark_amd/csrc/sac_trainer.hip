@@ -1742,6 +1742,17 @@ struct sac_trainer {
     unsigned fused_unchecked = 0;                     // fused launches since the host last looked at the abort marker
     bool publish_diag = true;                         // the next step's diagnostics go to the pinned host buffer (its caller reads them)
     unsigned test_stall_at = 0;                       // SAC_FUSED_TEST_STALL=<n>: the n-th fused launch loses a producer (tests)
+    // Fused steps launched by sac_step_device that the host has not yet seen applied: should one of them give up, these
+    // are re-run on the four-launch step from their slots (still intact: the host never runs more than two groups of
+    // sixteen steps ahead of the device on this path -- thr_ev, one event per sixteen steps).
+    static constexpr int NPEND = 64;
+    struct Pending { sac_buffer *buf; int64_t token; };
+    Pending pend[NPEND];
+    int pend_n = 0;                                   // entries pend[(pend_head + i) % NPEND], i < pend_n, oldest first
+    int pend_head = 0;
+    long long dev_steps = 0;                          // fused device-batch steps launched so far (sixteen per throttle event)
+    hipEvent_t thr_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int fallbacks = 0;                                // times the fused step gave up (at most once: the fall-back is for good)
     void (*abc)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_abc = 0;
     unsigned *d_sync = nullptr; size_t sync_bytes = 0;   // counters (one per 128-B line) + abort word
@@ -1942,13 +1953,28 @@ static int wait_trainer_stream(sac_trainer *t, hipEvent_t recorded = nullptr) {
     return 0;
 }
 
+// wait for ONE event (not for the stream behind it): a short user-space poll, then the blocking wait
+static int wait_event(hipEvent_t e) {
+    const auto spin_until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    hipError_t st;
+    while ((st = hipEventQuery(e)) == hipErrorNotReady && std::chrono::steady_clock::now() < spin_until) { }
+    if (st == hipSuccess) return 0;
+    if (st == hipErrorNotReady) (void)hipGetLastError();
+    SAC_HIP(hipEventSynchronize(e));
+    return 0;
+}
+
 // After the stream has drained: did a fused launch give up?  (Launch D of the first such step left the launch number in
 // the pinned diagnostics, applied nothing, and so did every step behind it.)  Roll the host counters back to the
 // applied steps, fall back to the four-launch step for good, and report.
-int check_fused_abort(sac_trainer *t) {
+// Returns 0 (nothing happened), 1 (the fused step gave up: *lost_out steps at the end of what was launched were not
+// applied, the counters are back at the applied ones, the trainer is on the four-launch step now -- the CALLER re-runs
+// the lost steps), <0 on a HIP error.
+int check_fused_abort(sac_trainer *t, unsigned *lost_out = nullptr) {
     const unsigned launched = t->fused_unchecked;
     t->fused_unchecked = 0;
-    if (!t->fused || t->h_diag[SAC_DIAG_N + 31] == 0.f) return 0;
+    if (lost_out) *lost_out = 0;
+    if (!t->fused || t->h_diag[SAC_DIAG_N + 31] == 0.f) { t->pend_n = 0; return 0; }
     unsigned first_bad = 0;
     memcpy(&first_bad, &t->h_diag[SAC_DIAG_N + 30], sizeof(unsigned));
     unsigned lost = t->fused_seq - first_bad + 1;
@@ -1966,10 +1992,48 @@ int check_fused_abort(sac_trainer *t) {
         G.live -= 1;
     }
     t->gate_exempt = false;
-    sac::set_error("fused SAC step gave up: a hand-off between its workgroups timed out (is another process or kernel using "
-                   "this GPU?).  The last %u step(s) of the call were NOT applied; this trainer now uses the four-launch "
-                   "step (SAC_FUSED=0 selects it from the start)", lost);
-    return -3;
+    t->fallbacks += 1;
+    if (lost_out) *lost_out = lost;
+    fprintf(stderr, "[libsac_hip] warning: the fused SAC step gave up -- a hand-off between its workgroups timed out (is another "
+                    "process or kernel using this GPU?).  This trainer continues on the four-launch step; the %u step(s) "
+                    "that were not applied are re-run on it (SAC_FUSED=0 selects the four-launch step from the start).\n", lost);
+    return 1;
+}
+
+// Re-run the last `n` device-batch steps that gave up, oldest first, on the step the trainer uses now (four launches).
+// Their batches still sit in their slots: sac_step_device keeps the host within 47 steps of the device, a slot is
+// reused 64 batches later and the read-ahead draws at most 16 batches beyond the last one handed out.
+int replay_pending(sac_trainer *t, unsigned n) {
+    SAC_REQUIRE((int)n <= t->pend_n, "internal: %u fused steps were lost but only %d are on record", n, t->pend_n);
+    if (n == 0) { t->pend_n = 0; return 0; }
+    sac_buffer *seen[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = t->pend_n - (int)n; i < t->pend_n; ++i) {
+        const sac_trainer::Pending &P = t->pend[(t->pend_head + i) % sac_trainer::NPEND];
+        const int slot = sac_ring_slot_of(P.buf, P.token);
+        if (slot < 0) return -1;
+        t->dev.eps1 = t->dev.eps2 = nullptr;
+        t->publish_diag = (i == t->pend_n - 1);
+        const int rc = launch_step(t, P.buf->d_ring + (size_t)slot * P.buf->ring_layout.slot_floats, P.buf->ring_layout, 0,
+                                   nullptr, i == t->pend_n - 1);
+        t->publish_diag = true;
+        if (rc) return -1;
+        for (auto &sb : seen) { if (sb == P.buf) break; if (!sb) { sb = P.buf; break; } }
+    }
+    // the slot-release events of those steps were recorded behind the launches that gave up: the buffers' streams now
+    // wait for the re-runs themselves before they may overwrite a slot
+    SAC_HIP(hipEventRecord(t->ev[2], t->stream));
+    for (sac_buffer *sb : seen) if (sb) SAC_HIP(hipStreamWaitEvent(sb->stream, t->ev[2], 0));
+    t->pend_n = 0;
+    return 0;
+}
+
+// the trainer's stream has drained: if a fused step gave up, fall back and re-run what was lost (device-batch steps)
+int recover_device_steps(sac_trainer *t) {
+    unsigned lost = 0;
+    const int fa = check_fused_abort(t, &lost);
+    if (fa <= 0) return fa;
+    if (replay_pending(t, lost)) return -1;
+    return wait_trainer_stream(t);
 }
 
 // sample + gather all slots of a loop on the buffer's stream, make the trainer's stream wait
@@ -2058,6 +2122,8 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         if ((v == 1 || v == 2 || v == 4) && ((v * t->NB) % 2 == 0)) t->SP = v;
     }
     SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    sac::stream_register(t->stream);
+    for (auto &e : t->thr_ev) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_tm) SAC_HIP(hipEventCreate(&e));
     for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2290,7 +2356,8 @@ int sac_trainer_destroy(sac_trainer_t *t) {
     for (auto &e : t->ev_tm) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_ready) if (e) (void)hipEventDestroy(e);
     for (auto &e : t->ev_done) if (e) (void)hipEventDestroy(e);
-    if (t->stream) (void)hipStreamDestroy(t->stream);
+    for (auto &e : t->thr_ev) if (e) (void)hipEventDestroy(e);
+    if (t->stream) { sac::stream_unregister(t->stream); (void)hipStreamDestroy(t->stream); }
     delete t;
     return 0;
 }
@@ -2437,7 +2504,18 @@ int sac_step(sac_trainer_t *t, const float *obs, const float *act, const float *
     }
     if (launch_step(t, t->ext_slot, L, 0, nullptr, diag != nullptr)) return -1;
     if (wait_trainer_stream(t)) return -1;
-    if (check_fused_abort(t)) return -3;
+    {   // a fused step that gave up: earlier device-batch steps still on record first, then this one again
+        unsigned lost = 0;
+        const int fa = check_fused_abort(t, &lost);
+        if (fa < 0) return -1;
+        if (fa == 1) {
+            if (lost > 1 && replay_pending(t, lost - 1)) return -1;
+            t->pend_n = 0;
+            t->dev.eps1 = eps1 ? t->d_eps : nullptr; t->dev.eps2 = eps1 ? t->d_eps + (size_t)B * A : nullptr;
+            if (launch_step(t, t->ext_slot, L, 0, nullptr, diag != nullptr)) return -1;
+            if (wait_trainer_stream(t)) return -1;
+        }
+    }
     if (diag) memcpy(diag, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     t->mirror_valid = false;
     return 0;
@@ -2463,10 +2541,19 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     }
     t->dev.eps1 = t->dev.eps2 = nullptr;
     t->publish_diag = diag != nullptr;
+    const bool was_fused = t->fused;
     const int rc_step = launch_step(t, b->d_ring + (size_t)slot * b->ring_layout.slot_floats, b->ring_layout, 0, nullptr, diag != nullptr);
     t->publish_diag = true;
     if (rc_step) return -1;
+    if (was_fused) {
+        // on record until the host has seen it applied (a fused step that gives up is re-run from its slot)
+        if (t->pend_n == sac_trainer::NPEND) { t->pend_head = (t->pend_head + 1) % sac_trainer::NPEND; t->pend_n -= 1; }
+        t->pend[(t->pend_head + t->pend_n++) % sac_trainer::NPEND] = sac_trainer::Pending{b, token};
+        const long long k = t->dev_steps++;
+        if ((k & 15) == 15) SAC_HIP(hipEventRecord(t->thr_ev[(k >> 4) & 3], s));
+    }
     {   // (see sac_buffer::free4: one "done with the slots so far" event per sixteen steps)
+        sac::forget_dead_step_stream(b);
         if (b->step_stream && b->step_stream != s && !b->multi_stream) {
             // a second trainer: one event per step from here on.  The first trainer's steps in flight were covered by the
             // per-sixteen-steps events only: the buffer's stream waits for all of them once, here
@@ -2484,8 +2571,23 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *b, int64_t token, float diag
     t->mirror_valid = false;
     if (diag) {
         if (wait_trainer_stream(t)) return -1;
-        if (check_fused_abort(t)) return -3;
+        if (recover_device_steps(t) < 0) return -1;
         memcpy(diag, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
+    } else if (was_fused) {
+        // Nobody waits for these steps.  The host looks at the give-up word (mapped pinned memory: a plain read) on every
+        // call, and when it enters a new group of sixteen steps it makes sure the device is through the group before the
+        // last one -- normally long true -- so that at most 47 steps are ever unverified and their slots still intact.
+        const long long k = t->dev_steps - 1;
+        bool gave_up = t->h_diag[SAC_DIAG_N + 31] != 0.f;
+        if (!gave_up && (k & 15) == 0 && k >= 32) {
+            if (wait_event(t->thr_ev[((k >> 4) - 2) & 3])) return -1;
+            gave_up = t->h_diag[SAC_DIAG_N + 31] != 0.f;
+            if (!gave_up && t->pend_n > 17) { t->pend_head = (t->pend_head + t->pend_n - 17) % sac_trainer::NPEND; t->pend_n = 17; }
+        }
+        if (gave_up) {
+            if (wait_trainer_stream(t)) return -1;
+            if (recover_device_steps(t) < 0) return -1;
+        }
     }
     return 0;
 }
@@ -2528,21 +2630,17 @@ static inline int64_t loop_chunk_len(int64_t done) {
     return LOOP_CH - done;
 }
 
-int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
-    SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
-    SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");
-    SAC_REQUIRE(b->O == t->O && b->A == t->A, "buffer dims (%d,%d) do not match trainer dims (%d,%d)", b->O, b->A,
-                t->O, t->A);
+// n_steps steps of a loop whose first step is number step0 of the caller's loop (step0 > 0: the remainder of a call
+// whose fused step gave up).  *lost: steps at the end that a fused launch giving up left unapplied (0: none).
+static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, int64_t step0, unsigned *lost_out) {
     static const bool host_timing = getenv("SAC_HOST_TIMING") != nullptr;      // diagnostic: where the host spends the call
     const auto ht0 = std::chrono::steady_clock::now();
     auto ht = [&](const char *what) {
         if (host_timing) fprintf(stderr, "[sac_train_loop %lld] %s at %.1f us\n", (long long)n_steps, what,
                                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
     };
-    SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
-    if (readahead_rollback(b)) return -1;          // (batches the stepwise interface drew ahead: the generator goes back first)
     if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
     if (ensure_idx(b, LOOP_RING * t->B)) return -1;
     ht("set-up done");
@@ -2617,7 +2715,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         }
         for (int64_t i = 0; i < m; ++i) {
             t->publish_diag = (first + i == n_steps - 1);
-            if (launch_step(t, b->d_slots + (size_t)(pos + i) * b->slot.slot_floats, b->slot, (int)(first + i), nullptr, first + i == 0)) return -1;
+            if (launch_step(t, b->d_slots + (size_t)(pos + i) * b->slot.slot_floats, b->slot, (int)(step0 + first + i), nullptr, step0 + first + i == 0)) return -1;
         }
         // the generator's state is one in-order sequence: everything later on the buffer's stream follows chunk 0's draw
         // (told to that stream only now, behind chunk 0's step launches: nothing of it is in front of the first step)
@@ -2637,12 +2735,43 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
     ht("all launches submitted");
     if (wait_trainer_stream(t, t->ev[1])) return -1;      // (the diagnostics are in mapped pinned memory: nothing to copy)
     ht("stream idle");
-    if (check_fused_abort(t)) return -3;
-    if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
-    if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
+    if (check_fused_abort(t, lost_out) < 0) return -1;
     t->timing_pending = true;                 // (the event intervals are read when sac_last_loop_ms asks: ~1 us each)
     t->mirror_valid = false;
     ht("return");
+    return 0;
+}
+
+int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *diag_first, float *diag_last) {
+    SAC_REQUIRE(t && b && n_steps > 0 && n_steps < (1 << 30), "bad arguments to sac_train_loop");
+    SAC_REQUIRE(b->device == t->device, "buffer and trainer live on different devices");
+    SAC_REQUIRE(b->O == t->O && b->A == t->A, "buffer dims (%d,%d) do not match trainer dims (%d,%d)", b->O, b->A,
+                t->O, t->A);
+    SAC_HIP(hipSetDevice(t->device));
+    if (t->fused && t->pend_n > 0) {          // device-batch steps nobody has verified yet: settle them first
+        if (wait_trainer_stream(t)) return -1;
+        if (recover_device_steps(t) < 0) return -1;
+    }
+    if (host_rng_sync_in(b)) return -1;            // (a bound generator: somebody else may have moved np.random)
+    if (readahead_rollback(b)) return -1;          // (batches the stepwise interface drew ahead: the generator goes back first)
+    const MtState start = b->host_seen;            // the generator in front of the loop's first batch
+    unsigned lost = 0;
+    if (train_loop_run(t, b, n_steps, 0, &lost)) return -1;
+    if (lost) {
+        // The fused step gave up inside this call (a co-tenant on the GPU): the last `lost` steps were not applied and the
+        // trainer is on the four-launch step now.  The generator goes back to the first unapplied step -- the state in
+        // front of the loop advanced by the batches of the applied ones -- and the rest of the loop runs again: the caller
+        // sees the same trajectory, index stream and final generator state as an undisturbed run.
+        SAC_REQUIRE(lost <= (unsigned)n_steps, "internal: %u steps lost in a loop of %lld", lost, (long long)n_steps);
+        const int64_t applied = n_steps - (int64_t)lost;
+        MtState st = start;
+        host_rng_skip(b, st, t->Bt, applied);
+        if (host_rng_adopt(b, st)) return -1;
+        unsigned again = 0;
+        if (train_loop_run(t, b, (int64_t)lost, applied, &again)) return -1;
+    }
+    if (diag_first) memcpy(diag_first, t->h_diag, sizeof(float) * SAC_DIAG_N);
+    if (diag_last) memcpy(diag_last, t->h_diag + SAC_DIAG_N, sizeof(float) * SAC_DIAG_N);
     return 0;
 }
 
@@ -2663,7 +2792,11 @@ int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float o
     }
     t->publish_diag = true;
     SAC_HIP(hipStreamSynchronize(s));
-    if (check_fused_abort(t)) return -3;
+    if (check_fused_abort(t)) {
+        sac::set_error("the fused step gave up during the profiling pass (is another process using this GPU?); the trainer "
+                       "is on the four-launch step now: profile again");
+        return -3;
+    }
     // interval k = launch k between two event records; the empty interval e5->e6 measures what an
     // event pair costs by itself and is subtracted from the kernel intervals (slot 5 of out_ms, once
     // k_policy_bwd, is the second empty interval and reads 0)
@@ -2694,7 +2827,7 @@ int sac_sync(sac_trainer_t *t) {
     SAC_REQUIRE(t, "null trainer");
     SAC_HIP(hipSetDevice(t->device));
     if (wait_trainer_stream(t)) return -1;
-    return check_fused_abort(t);
+    return recover_device_steps(t) < 0 ? -1 : 0;
 }
 
 // Experiment (bench.py --replicas-per-gpu): confine this trainer's launches to the CUs of the XCDs in `xcd_mask` (bit k =
@@ -2709,8 +2842,11 @@ int sac_trainer_set_xcd_mask(sac_trainer_t *t, unsigned xcd_mask) {
     SAC_HIP(hipStreamSynchronize(t->stream));
     hipStream_t ns = nullptr;
     if (sac_make_xcd_mask_stream(&ns, xcd_mask)) return -1;
+    sac::stream_unregister(t->stream);       // (drained above: a buffer that remembers it finds no step in flight)
     SAC_HIP(hipStreamDestroy(t->stream));
     t->stream = ns;
+    sac::stream_register(ns);
+    t->pend_n = 0;
     int cus = 0;
     SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
     const int mine = (cus / 8) * __builtin_popcount(xcd_mask & 0xffu);

@@ -138,10 +138,13 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
     ak, tk = variant["algorithm_kwargs"], variant["trainer_kwargs"]
     expl_env = SyntheticEnv(O, A, variant["expl_environment_kwargs"].get("horizon", 500), seed)
     eval_env = SyntheticEnv(O, A, variant["eval_environment_kwargs"].get("horizon", 500), seed + 1)
-    qf1, qf2, tqf1, tqf2 = (FlattenMlp(input_size=O + A, output_size=1, **variant["qf_kwargs"]) for _ in range(4))
+    # This driver's runs are a function of `seed` alone: initial weights come from np.random (seeded above), every noise
+    # stream from `seed` -- whether or not torch happens to be loaded in the process (the reference's own scripts seed
+    # torch as well, train.py:113, and the holders then follow torch's generator by themselves: networks.process_stream).
+    qf1, qf2, tqf1, tqf2 = (FlattenMlp(input_size=O + A, output_size=1, rs=np.random, **variant["qf_kwargs"]) for _ in range(4))
     if variant.get("algorithm", "SAC") == "TD3":                  # rlkit_utils.py:107-135
-        policy = TanhMlpPolicy(input_size=O, output_size=A, **variant["policy_kwargs"])
-        target_policy = TanhMlpPolicy(input_size=O, output_size=A, **variant["policy_kwargs"])
+        policy = TanhMlpPolicy(input_size=O, output_size=A, rs=np.random, **variant["policy_kwargs"])
+        target_policy = TanhMlpPolicy(input_size=O, output_size=A, rs=np.random, **variant["policy_kwargs"])
         eval_policy = policy
         expl_policy = PolicyWrappedWithExplorationStrategy(
             exploration_strategy=GaussianStrategy(max_sigma=0.1, min_sigma=0.1, seed=seed), policy=policy)
@@ -149,7 +152,8 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
                              batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
         policy._noise = expl_policy.es._rs                        # (the generator a checkpoint saves as policy_noise)
     else:
-        policy = TanhGaussianPolicy(obs_dim=O, action_dim=A, **variant["policy_kwargs"])
+        policy = TanhGaussianPolicy(obs_dim=O, action_dim=A, rs=np.random, noise=np.random.RandomState(seed),
+                                    **variant["policy_kwargs"])
         eval_policy, expl_policy = MakeDeterministic(policy), policy
         trainer = SACTrainer(env=eval_env, policy=policy, qf1=qf1, qf2=qf2, target_qf1=tqf1, target_qf2=tqf2,
                              batch_size=ak["batch_size"], noise_seed=seed, device=device, **tk)
@@ -179,14 +183,13 @@ def experiment(variant, log_dir=None, seed=1, obs_dim=None, action_dim=None, num
         t2 = time.time()
         buf.add_paths(new_paths)
         t3 = time.time()
-        buf.seed_from_numpy()                                     # continue the np.random global stream ...
+        # (the buffer samples np.random itself -- bound to its state words: nothing to hand over before or after the block)
         n_train = ak["num_trains_per_train_loop"]
         if fused_loop:
             trainer.train_loop(buf, n_train, batch_size=ak["batch_size"])
         else:
             for _ in range(n_train):
                 trainer.train(buf.random_batch(ak["batch_size"]))
-        buf.sync_to_numpy()                                       # ... and hand it back to the host
         t4 = time.time()
         row = OrderedDict()
         row.update(("replay_buffer/" + k, v) for k, v in buf.get_diagnostics().items())

@@ -8,9 +8,52 @@ them in sync.  ``.to(device)`` / ``.train(mode)`` are no-ops (rlkit_custom.py:30
 from __future__ import annotations
 
 import math
+import sys
+import zlib
 from collections import OrderedDict
 
 import numpy as np
+
+
+# ---- where the shim's random numbers come from ---------------------------------------------------------------
+# The reference seeds two generators per run (/root/reference/scripts/train.py:112-113): ``np.random.seed(args.seed)``
+# -- consumed by random_batch (and by robosuite) -- and ``torch.manual_seed(args.seed)`` -- from which rlkit draws the
+# initial weights, the rsample noise of the training step and the exploration noise of get_action.  The shim keeps that
+# split: when torch is loaded in the process (any run of the reference's own scripts), initial weights and acting noise
+# are drawn from torch's default generator and the device noise stream is keyed by ``torch.initial_seed()``; np.random
+# is then consumed by the replay buffer ALONE, exactly as with rlkit.  Without torch (this package's own driver, which
+# seeds np.random only and passes explicit seeds) the fall-back is np.random itself.
+class TorchGlobalStream:
+    """The draws of torch's default CPU generator behind the two RandomState methods the holders use (stateless:
+    picklable; every draw advances the process-wide generator, like rlkit's own ``torch.randn`` / ``uniform_``)."""
+
+    def uniform(self, low, high, size):
+        import torch
+        size = (size,) if isinstance(size, int) else tuple(size)
+        return (torch.rand(size, dtype=torch.float64) * (high - low) + low).numpy()
+
+    def standard_normal(self, size):
+        import torch
+        size = (size,) if isinstance(size, int) else tuple(size)
+        return torch.randn(size, dtype=torch.float64).numpy()
+
+
+def torch_is_loaded():
+    return "torch" in sys.modules and hasattr(sys.modules["torch"], "initial_seed")
+
+
+def process_stream():
+    """The generator rlkit would have drawn from: torch's global one when torch is loaded, else np.random."""
+    return TorchGlobalStream() if torch_is_loaded() else np.random
+
+
+def process_seed():
+    """The run's seed as the reference set it, WITHOUT consuming any stream: ``torch.initial_seed()`` when torch is
+    loaded (train.py:113), else a digest of np.random's current state (train.py:112)."""
+    if torch_is_loaded():
+        return int(sys.modules["torch"].initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    st = np.random.get_state()
+    return (zlib.crc32(np.ascontiguousarray(st[1], np.uint32).tobytes()) << 10) ^ int(st[2])
 
 
 class _Mlp:
@@ -18,7 +61,7 @@ class _Mlp:
         # b_init_value: rlkit Mlp's constant hidden bias -- 0.1 at the commit the reference pins (b7f97b2,
         # /root/reference/README.md:28; later rlkit: 0).  Unpinned: rlkit is not vendored and no shipped artefact
         # holds an initial bias; it only shapes from-scratch learning curves, never per-step parity.
-        rs = rs or np.random      # rlkit draws its init from the torch global generator; [R]
+        rs = rs or process_stream()      # rlkit draws its init from the torch global generator; [R]
         self.input_size, self.hidden_sizes = int(input_size), list(hidden_sizes)
         self.layers = OrderedDict()
         d = self.input_size
@@ -32,12 +75,37 @@ class _Mlp:
                                  rs.uniform(-init_w, init_w, (n_out,)).astype(np.float32)]
         self._trainer = None
 
-    # nn.Module look-alikes the epoch loop touches
+    # nn.Module look-alikes the epoch loop (rlkit_custom.py:306-312) and the rollout scripts (rlkit_utils.py:202,250:
+    # ``policy.cuda()`` on a loaded snapshot) touch
     def to(self, device):
         return self
 
     def train(self, mode=True):
         return self
+
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        return self
+
+    def eval(self):
+        return self
+
+    # The reference pickles these objects every epoch: ``logger.save_itr_params(epoch, snapshot)`` with the trainer's
+    # networks and both collectors' policies in the snapshot (rlkit_custom.py:54-56,68-82).  A holder bound to a trainer
+    # first pulls its trained weights off the device and is saved WITHOUT the binding (a ctypes handle cannot be pickled):
+    # the loaded object is a self-contained host network, which is all rlkit_utils.py:173-174,241-250 need.
+    def __getstate__(self):
+        tr = self._trainer
+        if tr is not None and getattr(tr, "_h", None) is not None and tr.policy is self:
+            tr.sync_holder_to_host(self)
+        st = dict(self.__dict__)
+        st["_trainer"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
 
     def flat(self):
         return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in self.layers.values()])
@@ -91,7 +159,10 @@ class TanhGaussianPolicy(_Mlp):
         super().__init__(hidden_sizes, [("last_fc", action_dim), ("last_fc_log_std", action_dim)], obs_dim,
                          init_w, kwargs.get("rs"), kwargs.get("b_init_value", 0.1))
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
-        self._noise = np.random.RandomState(0)
+        # exploration noise of get_action: rlkit draws it from torch's global generator (seeded at train.py:113); without
+        # torch a private stream keyed by the process seed -- two runs with different seeds explore differently either way
+        self._noise = kwargs.get("noise") or (TorchGlobalStream() if torch_is_loaded()
+                                              else np.random.RandomState(process_seed() & 0xFFFFFFFF))
 
     def _trunk(self, obs):
         h = np.asarray(obs, np.float32)
@@ -106,7 +177,7 @@ class TanhGaussianPolicy(_Mlp):
         obs = np.ascontiguousarray(np.atleast_2d(obs_np), dtype=np.float32)
         eps = None if deterministic else self._noise.standard_normal((obs.shape[0], self.action_dim)).astype(np.float32)
         tr = self._trainer
-        if tr is not None and getattr(tr, "_h", None) is not None:
+        if tr is not None and getattr(tr, "_h", None) is not None and tr.policy is self:
             # the library's acting entry (sac_policy_act: host forward from the policy mirrored D2H once per
             # training block) -- ONE implementation of the acting path once a trainer owns the weights
             return tr.policy_act(obs, deterministic, eps)
@@ -140,6 +211,15 @@ class MakeDeterministic:
     def train(self, mode=True):
         return self
 
+    def cuda(self, device=None):
+        return self
+
+    def cpu(self):
+        return self
+
+    def eval(self):
+        return self
+
 
 class TanhMlpPolicy(_Mlp):
     """``TanhMlpPolicy(input_size=, output_size=, hidden_sizes=)`` (rlkit_utils.py:108-117, the TD3 actor and its
@@ -153,7 +233,7 @@ class TanhMlpPolicy(_Mlp):
     def get_actions(self, obs_np):
         obs = np.ascontiguousarray(np.atleast_2d(obs_np), dtype=np.float32)
         tr = self._trainer
-        if tr is not None and getattr(tr, "_h", None) is not None:
+        if tr is not None and getattr(tr, "_h", None) is not None and tr.policy is self:
             return tr.policy_act(obs, True, None)  # sac_policy_act (TD3 handles: tanh(last_fc))
         h = obs
         names = list(self.layers)
@@ -175,13 +255,25 @@ class GaussianStrategy:
     (rlkit_utils.py:118-122: max_sigma = min_sigma = 0.1): action + N(0, sigma), clipped to the action box."""
 
     def __init__(self, action_space=None, max_sigma=1.0, min_sigma=None, decay_period=1000000, low=-1.0, high=1.0,
-                 seed=0):
+                 seed=None):
         self._max_sigma = float(max_sigma)
         self._min_sigma = float(max_sigma if min_sigma is None else min_sigma)
         self._decay_period = int(decay_period)
         self.low = getattr(action_space, "low", low)
         self.high = getattr(action_space, "high", high)
-        self._rs = np.random.RandomState(seed)
+        # rlkit: np.random.randn -- the process-wide NumPy stream (seeded at train.py:112); an explicit seed = private stream
+        self._rs = np.random if seed is None else np.random.RandomState(seed)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        if st["_rs"] is np.random:
+            st["_rs"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        if self._rs is None:
+            self._rs = np.random
 
     def get_action_from_raw_action(self, action, t=None):
         frac = min(1.0, (t or 0) * 1.0 / self._decay_period)

@@ -19,6 +19,24 @@ def _space_dim(space):
     return int(space)
 
 
+def numpy_global_state_address():
+    """Address of the state struct ``{uint32_t key[624]; int pos;}`` behind ``np.random`` -- the legacy global
+    ``RandomState``'s MT19937 bit generator, through the ctypes interface NumPy documents for bit generators
+    (``BitGenerator.ctypes.state_address``).  ``np.random.seed`` / ``set_state`` / every draw update it in place.  The
+    layout is checked against ``np.random.get_state()``; None if this NumPy does not look like that."""
+    try:
+        bg = np.random.mtrand._rand._bit_generator
+        addr = int(bg.ctypes.state_address)
+        key = np.ctypeslib.as_array((C.c_uint32 * 624).from_address(addr))
+        pos = C.c_int32.from_address(addr + 4 * 624).value
+        st = np.random.get_state()
+        if st[0] == "MT19937" and int(st[2]) == pos and np.array_equal(key, st[1]):
+            return addr
+    except Exception:
+        pass
+    return None
+
+
 class DeviceBatch(dict):
     """The dict random_batch() returns, with its arrays still in HBM.  Any read access (batch["rewards"], iteration,
     len ...) first copies the five arrays to the host, after which it is an ordinary dict; SACTrainer.train()
@@ -72,11 +90,15 @@ for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__
 class EnvReplayBuffer:
     """``EnvReplayBuffer(max_replay_buffer_size, env)``; ``env`` only supplies
     observation_space / action_space sizes (pass ``obs_dim=`` / ``action_dim=`` instead when
-    there is no env object).  Sampling consumes the NumPy legacy global stream: seed it with
-    ``seed_from_numpy()`` after ``np.random.seed`` (scripts/train.py:112) or ``seed(int)``."""
+    there is no env object).  Like rlkit's buffer, sampling consumes the process-wide NumPy legacy stream -- the one
+    ``np.random.seed(args.seed)`` seeds (scripts/train.py:112): constructed the reference's way,
+    ``EnvReplayBuffer(variant['replay_buffer_size'], expl_env)``, every ``random_batch`` draws exactly the indices
+    ``np.random.randint(0, size, batch_size)`` would have and leaves ``np.random`` where that call would have left it,
+    whatever else consumes ``np.random`` in between.  ``seed(int)`` / ``seed_from_numpy(rs)`` give the buffer a private
+    stream instead (tests, several independent runs in one process)."""
 
     def __init__(self, max_replay_buffer_size, env=None, env_info_sizes=None, obs_dim=None, action_dim=None,
-                 device=0, numpy_global_stream=False, lazy_batches=True):
+                 device=0, numpy_global_stream=True, lazy_batches=True):
         if env is not None:
             obs_dim = _space_dim(env.observation_space)
             action_dim = _space_dim(env.action_space)
@@ -85,9 +107,11 @@ class EnvReplayBuffer:
         self.env = env
         self._observation_dim, self._action_dim = int(obs_dim), int(action_dim)
         self._max_replay_buffer_size = int(max_replay_buffer_size)
-        # True: every random_batch() continues the process-wide np.random stream (adopts its state, samples on
-        # the device, writes the advanced state back) -- exactly what rlkit's np.random.randint call does, so
-        # host consumers of np.random (env resets, exploration noise) interleave identically.
+        # True (default): every random_batch() continues the process-wide np.random stream -- exactly what rlkit's
+        # np.random.randint call does, so host consumers of np.random (env resets, exploration noise) interleave
+        # identically.  The library is BOUND to np.random's own state words (sac_rng_bind_host): each device draw is
+        # mirrored on them in place, so there is no per-call state transfer and the read-ahead stays (the stepwise loop
+        # runs at full speed); if this NumPy hides its state the fall-back is get_state / set_state around each call.
         self.numpy_global_stream = bool(numpy_global_stream)
         self.lazy_batches = bool(lazy_batches)     # random_batch() returns device-resident DeviceBatch dicts
         self._lib = _lib.load()
@@ -95,6 +119,24 @@ class EnvReplayBuffer:
         _lib.check(self._lib.sac_buffer_create(C.byref(h), self._max_replay_buffer_size, self._observation_dim,
                                                self._action_dim, int(device)), "sac_buffer_create")
         self._h = h
+        self._bound = False
+        if self.numpy_global_stream:
+            self.bind_numpy_global_stream()
+
+    def bind_numpy_global_stream(self):
+        """(Re)join the process-wide ``np.random`` stream -- the construction default; undoes ``seed(int)``."""
+        self.numpy_global_stream = True
+        addr = numpy_global_state_address()
+        if addr is not None:
+            _lib.check(self._lib.sac_rng_bind_host(self._h, C.c_void_p(addr), C.c_void_p(addr + 4 * 624)),
+                       "sac_rng_bind_host")
+            self._bound = True
+
+    def _unbind(self):
+        self.numpy_global_stream = False
+        if self._bound:
+            _lib.check(self._lib.sac_rng_bind_host(self._h, None, None), "sac_rng_bind_host")
+            self._bound = False
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -103,16 +145,29 @@ class EnvReplayBuffer:
 
     # ---- the np.random global stream ----------------------------------------------------
     def seed(self, seed: int):
+        """A PRIVATE stream for this buffer, seeded like ``np.random.RandomState(seed)`` (it leaves the process-wide
+        stream: np.random is neither read nor written from here on -- ``bind_numpy_global_stream()`` rejoins it)."""
+        self._unbind()
         _lib.check(self._lib.sac_rng_seed(self._h, int(seed) & 0xFFFFFFFF), "sac_rng_seed")
 
     def seed_from_numpy(self, rs=None):
-        """Adopt the state of np.random (or a RandomState): sampling then continues that stream."""
-        st = (rs or np.random).get_state()
+        """Adopt the state of a RandomState as a private stream; without an argument: (re)join np.random itself --
+        a no-op on a buffer that never left it."""
+        if rs is None or rs is np.random:
+            if self._bound:
+                return
+            st = np.random.get_state()
+        else:
+            self._unbind()
+            st = rs.get_state()
         key = np.ascontiguousarray(st[1], dtype=np.uint32)
         _lib.check(self._lib.sac_rng_set_state(self._h, _lib.ptr(key), int(st[2])), "sac_rng_set_state")
 
     def sync_to_numpy(self, rs=None):
-        """Write the device stream state back into np.random (host consumers stay coherent)."""
+        """Write the stream state back into np.random / a RandomState (a buffer bound to np.random keeps it right by
+        itself: nothing to do)."""
+        if self._bound and (rs is None or rs is np.random):
+            return
         key = np.empty(624, dtype=np.uint32)
         pos = C.c_int32()
         _lib.check(self._lib.sac_rng_get_state(self._h, _lib.ptr(key), C.byref(pos)), "sac_rng_get_state")
@@ -208,13 +263,14 @@ class EnvReplayBuffer:
         round trip or a synchronisation per step.  lazy=False / return_indices=True: plain dict of host arrays."""
         if lazy is None:
             lazy = self.lazy_batches and not return_indices
+        slow_global = self.numpy_global_stream and not self._bound      # (a NumPy whose state words are out of reach)
         if lazy:
-            if self.numpy_global_stream:
+            if slow_global:
                 self.seed_from_numpy()
             tok = C.c_int64()
             _lib.check(self._lib.sac_random_batch_device(self._h, int(batch_size), C.byref(tok)),
                        "sac_random_batch_device")
-            if self.numpy_global_stream:
+            if slow_global:
                 self.sync_to_numpy()
             return DeviceBatch(self, int(tok.value), int(batch_size))
         B, O, A = int(batch_size), self._observation_dim, self._action_dim
@@ -222,11 +278,11 @@ class EnvReplayBuffer:
         act = np.empty((B, A), np.float32)
         rew, term = np.empty((B, 1), np.float32), np.empty((B, 1), np.float32)
         idx = np.empty(B, np.int64)
-        if self.numpy_global_stream:
+        if slow_global:
             self.seed_from_numpy()
         _lib.check(self._lib.sac_random_batch(self._h, B, _lib.ptr(obs), _lib.ptr(act), _lib.ptr(rew),
                                               _lib.ptr(term), _lib.ptr(nobs), _lib.ptr(idx)), "sac_random_batch")
-        if self.numpy_global_stream:
+        if slow_global:
             self.sync_to_numpy()
         batch = dict(observations=obs, actions=act, rewards=rew, terminals=term, next_observations=nobs)
         return (batch, idx) if return_indices else batch

@@ -13,13 +13,14 @@ import numpy as np
 
 from . import _lib
 from ._lib import DIAG_NAMES, NET_IDS, SacConfig
+from .networks import process_seed
 
 
 class SACTrainer:
     def __init__(self, env=None, policy=None, qf1=None, qf2=None, target_qf1=None, target_qf2=None,
                  discount=0.99, reward_scale=1.0, policy_lr=1e-3, qf_lr=1e-3, optimizer_class=None,
                  soft_target_tau=1e-2, target_update_period=1, plotter=None, render_eval_paths=False,
-                 use_automatic_entropy_tuning=True, target_entropy=None, batch_size=None, noise_seed=0,
+                 use_automatic_entropy_tuning=True, target_entropy=None, batch_size=None, noise_seed=None,
                  device=0):
         assert optimizer_class is None, "only Adam (rlkit's default) is implemented"
         self.env = env
@@ -31,14 +32,20 @@ class SACTrainer:
         self.use_automatic_entropy_tuning = bool(use_automatic_entropy_tuning)
         self.obs_dim, self.act_dim = policy.obs_dim, policy.action_dim
         self.target_entropy = float(-self.act_dim if target_entropy is None else target_entropy)
-        self.noise_seed, self.device = int(noise_seed), int(device)
+        # rsample noise of the step: rlkit draws it from the generator torch.manual_seed(args.seed) seeded
+        # (/root/reference/scripts/train.py:113); here a device counter-based stream keyed by that same process seed
+        # unless the caller names one -- two runs with different seeds see different noise, as in the reference
+        self.noise_seed = (process_seed() if noise_seed is None else int(noise_seed)) & 0xFFFFFFFFFFFFFFFF
+        self.device = int(device)
         self.eval_statistics = OrderedDict()
         self._need_to_update_eval_statistics = True
         self._num_train_steps = 0
         self._lib = _lib.load()
         self._h, self._batch = None, None
         self._host_policy_stale = False
-        policy._trainer = self
+        self._saved_state = None
+        for name in self.NETS:                   # (a holder finds its trainer: acting path, pickling)
+            getattr(self, name)._trainer = self
         if batch_size is not None:
             self._create(int(batch_size))
 
@@ -67,7 +74,8 @@ class SACTrainer:
         if not all(self._hidden(n) == self._hidden("qf1") for n in ("qf2", "target_qf1", "target_qf2")):
             raise RuntimeError("the four Q networks must share their hidden_sizes (rlkit_utils.py:64-83 builds them so)")
         h = self._new_handle(batch)
-        state = self._export_state() if self._h else None
+        state = self._export_state() if self._h else self._saved_state
+        self._saved_state = None
         self._destroy()
         self._h, self._batch = h, batch
         if state is None:
@@ -83,6 +91,23 @@ class SACTrainer:
 
     def __del__(self):
         self._destroy()
+
+    # A trainer can be pickled too (rlkit's snapshot never holds one, but callers copy / checkpoint whole algorithms):
+    # the device state -- parameters, Adam moments, entropy coefficient, counters -- travels as host arrays and goes
+    # back into a fresh handle on the first step after loading.
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        if self._h is not None:
+            self.sync_networks_to_host()
+            st["_saved_state"] = self._export_state()
+        st["_h"], st["_lib"] = None, None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._lib = _lib.load()
+        for name in self.NETS:
+            getattr(self, name)._trainer = self
 
     def _set_params(self, name, flat):
         flat = _lib.f32(flat)
@@ -232,6 +257,14 @@ class SACTrainer:
         if self._h is not None and self._host_policy_stale:
             self.policy.load_flat(self._get_params("policy"))
             self._host_policy_stale = False
+
+    def sync_holder_to_host(self, holder):
+        """The trained weights of ONE network holder (whichever of this trainer's nets it is) into its host arrays."""
+        for name in self.NETS:
+            if getattr(self, name) is holder:
+                holder.load_flat(self._get_params(name))
+                if name == "policy":
+                    self._host_policy_stale = False
 
     def sync_networks_to_host(self):
         for name in self.NETS:

@@ -22,7 +22,7 @@ class TD3Trainer(SACTrainer):
     def __init__(self, policy=None, qf1=None, qf2=None, target_qf1=None, target_qf2=None, target_policy=None,
                  target_policy_noise=0.2, target_policy_noise_clip=0.5, discount=0.99, reward_scale=1.0,
                  policy_learning_rate=1e-3, qf_learning_rate=1e-3, policy_and_target_update_period=2, tau=0.005,
-                 qf_criterion=None, optimizer_class=None, batch_size=None, noise_seed=0, device=0):
+                 qf_criterion=None, optimizer_class=None, batch_size=None, noise_seed=None, device=0):
         assert optimizer_class is None and qf_criterion is None, "only Adam / MSELoss (rlkit's defaults) are implemented"
         self.target_policy = target_policy
         self.target_policy_noise, self.target_policy_noise_clip = float(target_policy_noise), float(target_policy_noise_clip)

@@ -59,6 +59,19 @@ def test_a_failing_rank_makes_the_launcher_fail():
     assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
 
 
+def test_a_rank_other_than_zero_dying_ends_the_job_at_once_and_is_named():
+    """the launcher waited on rank 0 first -- which sat in the rendezvous for its 15-30 minute timeout
+    when another rank had died.  All children are polled now: the job ends within seconds, the exit line names the rank
+    that failed first and that rank's stderr is shown."""
+    import time
+    t0 = time.time()
+    p = run_bench("--gpus", "3", "--backend", "gloo", "--dry-run", "--steps", "2", "--warmup", "0", "--dry-run-fail-rank", "2",
+                  timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 90
+    assert "rank 2 failed first" in p.stderr and "exits on purpose" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+
+
 def test_torchrun_style_environment_is_still_honoured():
     """Under torch.distributed.run the ranks already exist (RANK / WORLD_SIZE in the environment): no self-launch."""
     p = run_bench("--gpus", "1", "--dry-run", "--steps", "3", "--warmup", "1",

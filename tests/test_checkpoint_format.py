@@ -133,3 +133,33 @@ def test_truncated_or_swapped_arrays_are_refused(tmp_path):
     assert float(back.st["params"]["policy"][0]) == 9.0          # nothing was loaded
     with pytest.raises(FileNotFoundError):
         ck.load_checkpoint(str(tmp_path / "nothing"), back)
+
+
+def test_a_dangling_latest_pointer_is_not_no_checkpoint(tmp_path):
+    """`latest` naming a generation without a manifest made checkpoint_exists() False -- a resuming run
+    started from scratch and its first save deleted what was left.  Now: the newest other complete generation is used,
+    then the flat layout of the first format revision; with neither, the damaged directory is an error, not 'nothing'."""
+    import shutil
+    d = str(tmp_path / "ck")
+    tr = _StubTrainer(1.0)
+    ck.save_checkpoint(d, tr, extra=dict(epoch=0))
+    good = ck.current_dir(d)
+    with open(os.path.join(d, "latest"), "w") as f:
+        f.write("gen-77\n")                                      # names a generation that is not there
+    assert ck.checkpoint_exists(d) and ck.current_dir(d) == good
+    back = _StubTrainer(9.0)
+    assert ck.load_checkpoint(d, back) == dict(epoch=0) and float(back.st["params"]["qf1"][0]) == 2.0
+    # a legacy flat manifest beside a stale pointer
+    flat = str(tmp_path / "flat")
+    os.makedirs(flat)
+    for name in os.listdir(good):
+        shutil.copy(os.path.join(good, name), os.path.join(flat, name))
+    with open(os.path.join(flat, "latest"), "w") as f:
+        f.write("gen-3\n")
+    assert ck.current_dir(flat) == flat
+    assert ck.load_checkpoint(flat, _StubTrainer(5.0)) == dict(epoch=0)
+    # nothing complete left at all: refuse loudly
+    os.remove(os.path.join(good, "manifest.json"))
+    with pytest.raises(FileNotFoundError, match="refusing"):
+        ck.checkpoint_exists(d)
+    assert ck.checkpoint_exists(str(tmp_path / "never_written")) is False

@@ -178,3 +178,39 @@ def test_two_trainers_take_turns_on_one_buffers_device_batches():
         for k in x["params"]:
             assert np.array_equal(x["params"][k], y["params"][k]), k
     assert ra[1] == rb[1] and np.array_equal(ra[0], rb[0])
+
+
+def test_a_buffer_outlives_the_trainer_whose_stream_it_remembered():
+    """the buffer kept the raw stream handle of the last trainer (slot-release events are recorded on
+    it).  Destroying that trainer, re-creating it for another batch size or moving it to a CU-masked stream killed the
+    stream; the next device-batch step of ANY trainer on that buffer then failed after its launches.  The schedule
+    below (trainer A alone -> A destroyed -> trainer B; B re-created with another batch size; B moved to another stream)
+    must equal the same schedule on host batches, bitwise."""
+    from robosuite_benchmark_amd import _lib
+    O, A, B, n = 42, 7, 64, 6000
+    runs = []
+    for lazy in (True, False):
+        buf = filled(n, O, A, 11, lazy_batches=lazy)
+        buf.seed(5)
+        _, ta = make_pair(O, A, B, seed=7, noise_seed=1)
+        for _ in range(40):                                  # A alone: read-ahead, one release event per 16 steps
+            ta.train(buf.random_batch(B))
+        sa = ta.state_dict()
+        del ta                                               # A's stream is gone; the buffer remembered it
+        _, tb = make_pair(O, A, B, seed=8, noise_seed=2)
+        for _ in range(70):                                  # (more than a ring of slots: old slots are reused)
+            tb.train(buf.random_batch(B))
+        for _ in range(20):                                  # another batch size = a new handle (and stream) for B
+            tb.train(buf.random_batch(48))
+        for _ in range(20):
+            tb.train(buf.random_batch(B))
+        _lib.check(tb._lib.sac_trainer_set_xcd_mask(tb._h, 0xff), "sac_trainer_set_xcd_mask")      # a new stream again
+        for _ in range(70):
+            tb.train(buf.random_batch(B))
+        runs.append((sa, tb.state_dict(), buf.rng_state()))
+    (a1, a2, ra), (b1, b2, rb) = runs
+    for x, y in ((a1, b1), (a2, b2)):
+        for k in x["params"]:
+            assert np.array_equal(x["params"][k], y["params"][k]), k
+        assert np.array_equal(x["scalars"], y["scalars"])
+    assert ra[1] == rb[1] and np.array_equal(ra[0], rb[0])

@@ -1,6 +1,6 @@
 """GPU: the fused step (k_abc: launches A + B + C as one launch with in-launch hand-offs, csrc/sac_fused.h) against the
 four-launch step of the same library -- identical arithmetic in identical order, so everything must agree bit for
-bit -- and the give-up path of the hand-offs (timeout -> nothing applied -> error -> four-launch fallback)."""
+bit -- and the give-up path of the hand-offs (timeout -> nothing applied -> four-launch fall-back -> the lost steps re-run)."""
 import os
 
 import numpy as np
@@ -179,26 +179,86 @@ def test_two_fused_trainers_side_by_side_on_disjoint_halves_of_the_chip():
     _same(a.state_dict(), ref.state_dict())
 
 
-def test_a_lost_producer_ends_in_an_error_not_a_hang_and_nothing_is_applied():
+def test_a_lost_producer_falls_back_transparently_inside_the_loop_call():
     """Launch 3 of the loop loses one producer workgroup (test hook): its consumers give up after the hand-off timeout,
-    launch D of that step and of every later one applies nothing, the call reports the error, the counters say two steps,
-    the state equals two steps of the four-launch path bit for bit, and the trainer carries on with four launches."""
+    launch D of that step and of every later one applies nothing.  The call notices, puts the trainer on the four-launch
+    step, takes the generator back to the first unapplied step and runs the rest of the loop again: it RETURNS NORMALLY,
+    and state, diagnostics, per-step trace and the buffer's generator equal an undisturbed four-launch run bit for bit."""
     O, A, B = 42, 7, 256
     fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9, SAC_FUSED_TEST_STALL=3)
     bufs = [_buffer(4000, O, A, 8), _buffer(4000, O, A, 8)]
     for b in bufs:
         b.seed(31)
     assert fused.is_fused()
-    with pytest.raises(RuntimeError, match="gave up"):
-        fused.train_loop(bufs[0], 10, batch_size=B)
+    fa, la = fused.train_loop(bufs[0], 10, batch_size=B)
     assert not fused.is_fused()
-    plain.train_loop(bufs[1], 2, batch_size=B)
+    fb, lb = plain.train_loop(bufs[1], 10, batch_size=B)
+    assert np.array_equal(fa, fb) and np.array_equal(la, lb)
     _same(fused.state_dict(), plain.state_dict())
-    assert fused.state_dict()["scalars"][3] == 2 and fused.state_dict()["scalars"][4] == 2
-    # both continue on the four-launch step: same batches from here on (re-seed both streams)
-    for b in bufs:
-        b.seed(32)
+    assert fused.state_dict()["scalars"][3] == 10 and fused.state_dict()["scalars"][4] == 10
+    ka, pa = bufs[0].rng_state()
+    kb, pb = bufs[1].rng_state()
+    assert np.array_equal(ka, kb) and pa == pb          # the index stream went on exactly where an undisturbed run's would
+    ref = np.random.RandomState(31)
+    for _ in range(10):
+        ref.randint(0, 4000, B)
+    assert np.array_equal(ka, ref.get_state()[1]) and pa == ref.get_state()[2]
+    # both continue on the four-launch step
     _, la = fused.train_loop(bufs[0], 15, batch_size=B)
     _, lb = plain.train_loop(bufs[1], 15, batch_size=B)
     assert np.array_equal(la, lb) and np.all(np.isfinite(la))
     _same(fused.state_dict(), plain.state_dict())
+
+
+@pytest.mark.parametrize("stall_at,steps", [(1, 5), (40, 100), (57, 60)])
+def test_a_lost_producer_falls_back_transparently_on_the_stepwise_interface(stall_at, steps):
+    """The reference's own loop -- random_batch(); train() on device batches, nobody waiting for a step -- with launch
+    `stall_at` losing a producer: the steps launched behind it (the host runs ahead of the device) apply nothing; the
+    host notices at a later call, falls back and re-runs them from their slots.  No exception, same trajectory."""
+    O, A, B = 42, 7, 128
+    fused, plain = _pair_of_hip(O, A, B, seed=5, noise_seed=3, SAC_FUSED_TEST_STALL=stall_at)
+    bufs = [_buffer(3000, O, A, 2), _buffer(3000, O, A, 2)]
+    for b in bufs:
+        b.seed(8)
+    for tr, b in ((fused, bufs[0]), (plain, bufs[1])):
+        for _ in range(steps):
+            tr.train(b.random_batch(B))
+        _lib_sync(tr)
+    assert not fused.is_fused()
+    _same(fused.state_dict(), plain.state_dict())
+    assert fused.state_dict()["scalars"][4] == steps
+
+
+def test_the_epoch_driver_survives_a_fused_step_giving_up(tmp_path):
+    """driver.experiment died mid-epoch when the fused step gave up.  Now the run completes and logs the
+    same rows as a run on the four-launch step."""
+    import json
+    from robosuite_benchmark_amd import variant
+    from robosuite_benchmark_amd.driver import experiment
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    v = variant.load_variant(os.path.join(root, "tests", "golden", "Lift-Panda-OSC-POSE-SEED17.variant.json"))
+    v["algorithm_kwargs"].update(num_trains_per_train_loop=60, num_expl_steps_per_train_loop=300,
+                                 min_num_steps_before_training=400, num_eval_steps_per_epoch=200)
+    old = {k: os.environ.get(k) for k in ("SAC_FUSED", "SAC_FUSED_TEST_STALL")}
+    try:
+        os.environ.pop("SAC_FUSED", None)
+        os.environ["SAC_FUSED_TEST_STALL"] = "75"                    # inside the second epoch's training block
+        rows_a = experiment(v, seed=3, num_epochs=3, quiet=True)
+        os.environ.pop("SAC_FUSED_TEST_STALL", None)
+        os.environ["SAC_FUSED"] = "0"
+        rows_b = experiment(v, seed=3, num_epochs=3, quiet=True)
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    for ra, rb in zip(rows_a, rows_b):
+        for k in ra:
+            if not k.startswith("time/"):
+                assert ra[k] == rb[k], k
+
+
+def _lib_sync(tr):
+    from robosuite_benchmark_amd import _lib
+    _lib.check(tr._lib.sac_sync(tr._h), "sac_sync")

@@ -211,9 +211,11 @@ def test_asynchronous_ingest_is_ordered_before_sampling_and_frees_the_callers_ar
                                    terminals=host._term[want_idx], next_observations=host._next_obs[want_idx]))
 
 
-def test_ingest_overlaps_host_work():
-    """While the copy engine moves one staging buffer the host is free: a 60 000-row insert (eight staging chunks)
-    still has rows in flight when the call returns, and polling never blocks."""
+def test_a_large_insert_cycles_both_staging_buffers_and_lands_in_ring_order():
+    """A 60 000-row insert (eight staging chunks through two pinned buffers, wrapping the ring): polling never blocks,
+    waiting ends with nothing pending, and the rows sit where the ring arithmetic says.  (Whether rows are still in
+    flight when the call returns depends on the link and is measured, not asserted: bench.py's "ingest" entry reports
+    call_returns_us / landed_us.)"""
     from robosuite_benchmark_amd import EnvReplayBuffer
     O, A, n = 379, 6, 60_000                                # Wipe-sized rows: 3 KB each, 180 MB in all
     dev = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
@@ -223,10 +225,9 @@ def test_ingest_overlaps_host_work():
     dev.add_block(o[:100], a[:100], r[:100], no[:100], np.zeros(100, np.uint8))     # staging buffers exist now
     dev.ingest_wait()
     dev.add_block(o, a, r, no, np.zeros(n, np.uint8))
-    pending_at_return = dev.ingest_pending()                # the last chunk's 25 MB are still on the PCIe link
+    assert isinstance(dev.ingest_pending(), bool)           # (a poll, whatever it says: it returns at once)
     dev.ingest_wait()
     assert dev.ingest_pending() is False
-    assert pending_at_return in (True, False)               # (timing-dependent; reported by bench.py's "ingest" entry)
     got = dev.gather(np.array([0, 99, 100, n - 1] * 4, dtype=np.int64))
     # the ring head stood at 100: storage[100:] = o[:n-100], storage[:100] = o[n-100:]
     assert np.array_equal(got["observations"][:4], o[[n - 100, n - 1, 0, n - 101]])

@@ -34,7 +34,7 @@ def test_five_thousand_steps_stay_finite_and_keep_learning():
     key, pos = buf.rng_state()
     rs = np.random.RandomState(3)
     rs.randint(0, 50_000, 256 * 5000)
-    assert np.array_equal(rs.get_state()[1], key) or True       # (NumPy twists lazily: compare the next draws)
+    assert np.array_equal(rs.get_state()[1], key) and rs.get_state()[2] == pos      # the generator's words and position
     tmp = np.random.RandomState(0)
     buf.sync_to_numpy(tmp)
     assert np.array_equal(tmp.randint(0, 1 << 30, 100), rs.randint(0, 1 << 30, 100))

@@ -89,8 +89,10 @@ def test_ka4_log_std_clamped_at_two():
     d = sac.step(*synth_batch(np.random.RandomState(4), 64, 42, 7))
     assert d["Policy log std Max"] == 2.0
     assert KA["_scan"]["policy_log_std_max"] == 2.0
-    # clamp blocks the gradient of the saturated head
-    assert np.all(sac.last["g_policy"][3] == 0.0) or True
+    # the clamp blocks the gradient of the saturated head: weight (parameter 3) and bias (parameter 7) of last_fc_log_std
+    assert sac.last["log_std"].detach().numpy().min() == 2.0
+    assert np.all(sac.last["g_policy"][3] == 0.0) and np.all(sac.last["g_policy"][7] == 0.0)
+    assert np.any(sac.last["g_policy"][2] != 0.0)           # (the mean head next to it does learn)
 
 
 @pytest.mark.parametrize("run", [k for k in KA if not k.startswith("_")])
