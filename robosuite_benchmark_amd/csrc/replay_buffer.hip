@@ -500,7 +500,11 @@ int launch_sample(sac_buffer *b, int batch, int64_t n_batches, int64_t idx_offse
     mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
     hipLaunchKernelGGL(k_mt_randint, dim3(1), dim3(256), 0, q, b->d_rng, rng, mask, count, dst, batch, bp);
     SAC_HIP(hipGetLastError());
-    if (!b->ra_internal) host_rng_advance(b, batch, n_batches);      // (behind the launch: the device draws meanwhile)
+    // (behind the launch: the device draws meanwhile; a loop mirrors all its chunks in one go once everything is queued)
+    if (!b->ra_internal) {
+        if (b->defer_mirror) b->deferred_batches += n_batches;
+        else host_rng_advance(b, batch, n_batches);
+    }
     return 0;
 }
 

@@ -161,6 +161,8 @@ struct sac_buffer {
     // noticed by comparing those words with host_seen in front of the next draw.
     uint32_t *host_key = nullptr; int32_t *host_pos = nullptr;
     sac::MtState host_seen{};
+    bool defer_mirror = false;                       // sac_train_loop: the mirror follows once all launches are queued
+    int64_t deferred_batches = 0;
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
 };
 

@@ -2666,6 +2666,13 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
     }
     int64_t done = 0, pos = 0;
     int timed = 0;
+    // the host mirror of the generator (sac_buffer::host_seen; np.random's own words when bound) follows in ONE piece
+    // behind the last launch: ~1.3 us of host time per batch that no launch of this call has to wait for
+    struct MirrorLater {
+        sac_buffer *b; int batch;
+        ~MirrorLater() { b->defer_mirror = false; if (b->deferred_batches) host_rng_advance(b, batch, b->deferred_batches); b->deferred_batches = 0; }
+    } mirror_later{b, t->Bt};
+    b->defer_mirror = true; b->deferred_batches = 0;
     for (int c = 0; done < n_steps; ++c) {
         const int64_t first = done, want = loop_chunk_len(done);
         int64_t m = (n_steps - first < want) ? n_steps - first : want;
@@ -2733,6 +2740,10 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
     }
     SAC_HIP(hipEventRecord(t->ev[1], s));
     ht("all launches submitted");
+    b->defer_mirror = false;
+    host_rng_advance(b, t->Bt, b->deferred_batches);
+    b->deferred_batches = 0;
+    ht("generator mirrored on the host");
     if (wait_trainer_stream(t, t->ev[1])) return -1;      // (the diagnostics are in mapped pinned memory: nothing to copy)
     ht("stream idle");
     if (check_fused_abort(t, lost_out) < 0) return -1;

@@ -238,7 +238,8 @@ def test_the_epoch_driver_survives_a_fused_step_giving_up(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     v = variant.load_variant(os.path.join(root, "tests", "golden", "Lift-Panda-OSC-POSE-SEED17.variant.json"))
     v["algorithm_kwargs"].update(num_trains_per_train_loop=60, num_expl_steps_per_train_loop=300,
-                                 min_num_steps_before_training=400, num_eval_steps_per_epoch=200)
+                                 min_num_steps_before_training=400, num_eval_steps_per_epoch=200,
+                                 expl_max_path_length=100, eval_max_path_length=100)
     old = {k: os.environ.get(k) for k in ("SAC_FUSED", "SAC_FUSED_TEST_STALL")}
     try:
         os.environ.pop("SAC_FUSED", None)

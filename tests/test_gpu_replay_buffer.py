@@ -85,8 +85,8 @@ def test_full_size_buffer_indices_and_draw_count():
 @pytest.mark.parametrize("O,A", [(42, 7), (46, 7), (89, 14), (379, 6), (3, 1)])
 def test_random_batch_bit_exact_vs_host_buffer(O, A):
     host, dev = make_buffers(5000, 5000, O, A, seed=3)
-    np.random.seed(17)
-    dev.seed_from_numpy()
+    np.random.seed(17)                        # the reference-shaped host buffer draws from np.random itself ...
+    dev.seed(17)                              # ... the device buffer from a PRIVATE copy of the same stream
     for B in (16, 128, 256):
         want, widx = host.random_batch(B)
         got, gidx = dev.random_batch(B, return_indices=True)
@@ -96,7 +96,7 @@ def test_random_batch_bit_exact_vs_host_buffer(O, A):
     ref = np.random.RandomState(17)
     for B in (16, 128, 256):
         ref.randint(0, 5000, B)
-    dev.sync_to_numpy()
+    dev.sync_to_numpy()                       # (a private stream written back explicitly)
     assert np.array_equal(np.random.randint(0, 99, 50), ref.randint(0, 99, 50))
 
 
