@@ -556,7 +556,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     fl_all = flops_per_kernel(B, O, A)
     step_kernels = [k for k in prof if k.startswith("k_") and k not in ("k_gather", "k_mt_randint") and prof[k] > 0]
     # a fused launch carries the FLOPs of the launches it replaces ("k_fwd_abc" = a + b + c ...)
-    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd")}
+    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_chain": ("k_fwd_a", "k_fwd_b")}
     fl = {k: (sum(fl_all[p] for p in fused_parts[k]) if k in fused_parts else fl_all[k]) for k in step_kernels}
     kern = {}
     for k, f in fl.items():

@@ -96,6 +96,7 @@ SYMBOLS = {
     "sac_train_loop": (C.c_int, [_P, _P, C.c_int64, _P, _P]),
     "sac_sync": (C.c_int, [_P]),
     "sac_trainer_is_fused": (C.c_int, [_P]),
+    "sac_trainer_step_kind": (C.c_int, [_P]),
     "sac_last_loop_ms": (C.c_int, [_P, _F, _F, _F, _F]),
     "sac_profile_loop": (C.c_int, [_P, _P, C.c_int64, _P]),
     "sac_measure_peaks": (C.c_int, [C.c_int, _F]),

@@ -1693,6 +1693,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 }
 
 #include "sac_fused.h"
+#include "sac_chain.h"
 
 }  // namespace sac
 
@@ -1760,6 +1761,10 @@ struct sac_trainer {
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     void (*bwd)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
     size_t lds_fa = 0, lds_fb = 0;
+    // column split 1 (batch >= 1024): launches A + B as one launch without any hand-off (k_chain, sac_chain.h)
+    bool chain = false;
+    void (*chaink)(Dev, const float *, SlotLayout, StepArg) = nullptr;
+    size_t lds_chain = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
 };
 
@@ -1922,10 +1927,15 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
         }
         if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); SAC_HIP(hipEventRecord(ev[3], s)); }
     } else {
-        hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
-        if (ev) SAC_HIP(hipEventRecord(ev[1], s));
-        hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
-        if (ev) SAC_HIP(hipEventRecord(ev[2], s));
+        if (t->chain) {
+            hipLaunchKernelGGL(t->chaink, dim3(4 * NB), dim3(256), t->lds_chain, s, d, S, SL, sa);
+            if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); }
+        } else {
+            hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
+            if (ev) SAC_HIP(hipEventRecord(ev[1], s));
+            hipLaunchKernelGGL(t->fwd_b, dim3(4 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sa);
+            if (ev) SAC_HIP(hipEventRecord(ev[2], s));
+        }
         const int compact = (3 * SPv * NB <= 192) ? 1 : 0;     // see k_bwd
         hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sa, compact);
         if (ev) SAC_HIP(hipEventRecord(ev[3], s));
@@ -2317,6 +2327,24 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
             if (!G.ev) SAC_HIP(hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
             G.live += 1;
         }
+    }
+    {   // column split 1: the forward launches as one (sac_chain.h); SAC_CHAIN=0: the four-launch step (A/B comparisons)
+        const char *e = getenv("SAC_CHAIN");
+        t->lds_chain = sizeof(float) * (size_t)(RB * KL0q + 2 * RB * H + 4 * nth * 256 + RB * 32);
+        // Where it pays (measured, scripts/large_batch_matrix.sh): one round of workgroups (4 NB <= CUs: batch 1024) and first
+        // layers of at most eight k-chunks -- Door 46/7 58.1 -> 54.8 us per step, TwoArmHandoff 86/14 64.9 -> 64.2; batch 2048
+        // (two rounds of 350-register workgroups) and Wipe's 25-chunk first layers (recomputed by both P items) lose.
+        int cus = 0;
+        SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
+        const bool pays = (4 * t->NB <= cus && t->KQ <= 128) || (e && atoi(e) == 1);
+        t->chain = !td3 && !t->fused && t->SP == 1 && (t->NB % 2) == 0 && t->lds_chain <= 160 * 1024 - 512 && pays && !(e && atoi(e) == 0);
+        {
+            const bool wide4 = t->KQ > 64;       // first layers of more than four k-chunks
+            t->chaink = (nth == 1) ? (wide4 ? &k_chain<1, true> : &k_chain<1, false>) : (wide4 ? &k_chain<2, true> : &k_chain<2, false>);
+        }
+        if (t->chain && t->lds_chain > 64 * 1024)
+            SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->chaink), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)t->lds_chain));
     }
     if (t->lds_fa > 64 * 1024)
         SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->fwd_a),
@@ -2885,6 +2913,7 @@ int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
 
 // 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step
 int sac_trainer_is_fused(const sac_trainer_t *t) { return (t && t->fused) ? 1 : 0; }
+int sac_trainer_step_kind(const sac_trainer_t *t) { return !t ? -1 : (t->fused ? 1 : (t->chain ? 2 : 0)); }
 
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms) {
     SAC_REQUIRE(t, "null trainer");

@@ -210,16 +210,18 @@ class SACTrainer:
         names = ["k_mt_randint", "k_gather", "k_fwd_a", "k_fwd_b", "k_bwd", "reserved", "k_dw_adam",
                  "event_pair", "steps_wall"]
         mode = self.fused_mode()
-        if mode:                     # the fused step: k_abc = launches A + B + C in one (the next two slots read 0)
+        if mode == 1:                # the fused step: k_abc = launches A + B + C in one (the next two slots read 0)
             names[2], names[3], names[4] = "k_fwd_abc", "fused_b", "fused_c"
+        elif mode == 2:              # column split 1: k_chain = launches A + B in one (the next slot reads 0)
+            names[2], names[3] = "k_chain", "chain_b"
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
     def fused_mode(self):
-        """0: four launches per step; 1: the fused step, k_abc + k_dw_adam."""
-        return int(self._lib.sac_trainer_is_fused(self._h)) if self._h is not None else 0
+        """0: four launches per step; 1: the fused step, k_abc + k_dw_adam; 2: k_chain + k_bwd + k_dw_adam (batch >= 1024)."""
+        return int(self._lib.sac_trainer_step_kind(self._h)) if self._h is not None else 0
 
     def is_fused(self):
-        return self.fused_mode() > 0
+        return self.fused_mode() == 1
 
     def loop_timing_ms(self):
         v = [C.c_float() for _ in range(4)]
