@@ -128,8 +128,7 @@ struct DwLayer {
     float *TP, *Tbias;             // Polyak target (forward copy / bias) or null
     int N, K, ldp, ldt, nk, job0, xt_from_slot;
     float lr;
-    int k_base, nt;                // first column of this entry's strips (a first layer's partial last strip is an entry of its
-                                   // own); tiles per job: 4, or the whole row of a 65-112-column first layer (5-7)
+    int k_base, pad_;              // first column of this entry's strips (a first layer's partial last strip is an entry of its own)
 };
 constexpr int NDW = 12;           // 3 nets x 3 layers + the tail strips of the first layers (see build_table)
 struct DwTable {                   // L: device array, read with scalar loads
@@ -1384,179 +1383,6 @@ __device__ __forceinline__ void td3_diagnostics(const Dev &d, const StepArg &sa,
     }
 }
 
-// The tile-owner body of one weight-gradient job (see dw_adam_body): MT = tiles of 16 input columns the job may hold.
-// Tile t is contracted by every wave over its share of the batch and OWNED (reduction over the waves, Adam, both weight
-// copies, Polyak) by wave t & 3: with MT = 7 a wave owns up to two tiles.  Per tile the arithmetic and its order are the
-// same whatever MT is, so a first layer's row as ONE job gives bit for bit what its two strips gave.
-template <int MT>
-__device__ __forceinline__ void dw_tile_job(const Dev &d, const DwLayer &J, const float *__restrict__ S, const StepArg &sa,
-                                            float *red, float *redb, float *trs, int jb, unsigned aborted) {
-    const int B = d.B;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & 15, g = lane >> 4;
-    const bool keep_grad = (sa.pad2 & 2u) != 0;
-    constexpr int NO = (MT > 4) ? 2 : 1;          // tiles a wave may own
-    {
-        const int jj = jb - J.job0;
-        const int n0 = 16 * (jj / J.nk), k0 = J.k_base + 64 * (jj % J.nk);
-        // owner of tile t: wave t & 3; lane (c = r, g) holds rows n0+4g+i, col k0 + 16*t + c
-        int k_own[NO];
-        bool own_valid[NO];
-        size_t ot[NO];                                           // this lane's 16 B of the transposed copy / Adam moments
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            k_own[o] = k0 + 16 * (wave + 4 * o) + r;
-            own_valid[o] = k_own[o] < J.K && (wave + 4 * o) < MT;
-            ot[o] = frag_off(own_valid[o] ? k_own[o] : k0 + r, n0 + 4 * g, J.ldt);
-        }
-        // dY^T and X^T are fragment-major [feature][batch]: feature tile f, batch chunk q = 1 KB at ((f * B/16) + q) * 256
-        const size_t tile_floats = (size_t)(B >> 4) * 256;
-        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)(k0 >> 4) * tile_floats;
-        const float *YT = J.dYT + (size_t)(n0 >> 4) * tile_floats;
-        const int per = (B / 16) / 4;                 // 16-row chunks of the batch per wave
-        const int rem = (B / 16) - 4 * per;
-        const int s0 = wave * per + (wave < rem ? wave : rem);
-        const int s1 = s0 + per + (wave < rem ? 1 : 0);
-        const float *yp = YT + 4 * lane;              // this lane's 16 B of a fragment: (feature r, batch rows 4g..4g+3)
-        const float *xp = XT + 4 * lane;
-        f32x4 acc[MT] = {};
-        float bsum = 0.f;
-        // first group of operand loads, then the owner's state, then the scalars: all in flight together.
-        // Loads are unconditional (clamped chunk index, select on the loaded VALUE): a conditional load
-        // becomes a branch whose merge point needs the data, i.e. a vmcnt(0) right behind the load.
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        auto chunk_of = [&](int sq) { const int m = (sq < s1 - 1) ? sq : s1 - 1; return m > 0 ? m : 0; };
-        // k tiles of this strip that lie inside the layer (a first layer of 80 input columns has a second strip with ONE):
-        // a padding tile re-reads the last valid one -- lines that are in flight anyway -- instead of streaming 16 KB of
-        // zero (or foreign) rows; its products are never used (tile_ok below)
-        int nv = (J.ldp - k0) >> 4;
-        nv = nv > MT ? MT : (nv < 1 ? 1 : nv);
-        size_t toff[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) toff[t] = (size_t)(t < nv ? t : nv - 1) * tile_floats;
-        f32x4 a[4], b[4][MT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int cq = chunk_of(s0 + u);
-            a[u] = ld4(yp + 256 * cq);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
-        }
-        f32x4 p4[NO], m4[NO], v4[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            p4[o] = zero4; m4[o] = zero4; v4[o] = zero4;
-            if (own_valid[o]) {
-                p4[o] = ld4(J.PT + ot[o]);
-                m4[o] = ld4(J.MT + ot[o]);
-                v4[o] = ld4(J.VT + ot[o]);
-            }
-        }
-        const double bc1 = sa.bc1, bc2sd = sa.bc2s;
-        const bool polyak = (J.TP != nullptr) && (sa.step_now % d.period == 0);
-        // The forward copy P [n][k] (and the Polyak target, same layout) holds this wave's 16 x 16 tile as ONE contiguous
-        // 1-KB block, lane (c', g') = (n0 + c', k 4g'..4g'+3): written below with one 16-B store per lane after a
-        // transpose through LDS (four 4-B stores + four 4-B target loads per lane before: the launch ends when its stores
-        // have drained).
-        bool tile_ok[NO];                                                  // (wave-uniform: the last k tile of a 48-wide layer)
-        size_t pblk[NO];
-        f32x4 tp4[NO];
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            tile_ok[o] = (k0 + 16 * (wave + 4 * o)) < J.ldp && (wave + 4 * o) < MT;
-            pblk[o] = frag_off(n0, tile_ok[o] ? k0 + 16 * (wave + 4 * o) : k0, J.ldp) + 4 * lane;
-            tp4[o] = zero4;
-            if (polyak && tile_ok[o]) tp4[o] = ld4(J.TP + pblk[o]);
-        }
-        float pb = 0.f, mbv = 0.f, vbv = 0.f, tbv = 0.f;
-        const bool bias_lane = (k0 == 0) && threadIdx.x < 16 && (n0 + (int)threadIdx.x) < J.N;
-        if (bias_lane) {
-            const int n = n0 + threadIdx.x;
-            pb = ld1g(J.bias + n); mbv = ld1g(J.mb + n); vbv = ld1g(J.vb + n);
-            if (polyak) tbv = ld1g(J.Tbias + n);
-        }
-#ifdef SAC_STAMPS
-        { float probe = a[0][0] + b[3][3][3]; asm volatile("" :: "v"(probe)); }
-        STAMP(4, 4);
-#endif
-        for (int sI = s0; sI < s1; sI += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const f32x4 au = (sI + u < s1) ? a[u] : zero4;
-                bsum += (au[0] + au[1]) + (au[2] + au[3]);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[i], b[u][t][i], acc[t], 0, 0, 0);
-                }
-            }
-            if (sI + 4 < s1) {                       // batches above 256 rows: next group
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int cq = chunk_of(sI + 4 + u);
-                    a[u] = ld4(yp + 256 * cq);
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) st4(red + ((wave * MT + t) * 64 + lane) * 4, acc[t]);
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (g == 0) redb[wave * 16 + r] = bsum;
-        lds_barrier();
-        STAMP(4, 1);
-        const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
-        if (aborted) return;
-#pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            if (!tile_ok[o]) continue;
-            const int tl = wave + 4 * o;                                    // the tile this wave owns
-            f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) gsum += ld4(red + ((w * MT + tl) * 64 + lane) * 4);
-            if (own_valid[o]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = n0 + 4 * g + i;
-                    if (n < J.N) {
-                        float p = p4[o][i], m = m4[o][i], v = v4[o][i];
-                        adam_update(p, m, v, gsum[i], step_size, bc2s);
-                        p4[o][i] = p; m4[o][i] = m; v4[o][i] = v;
-                        if (J.G && keep_grad) st1g(J.G + frag_off(n, k_own[o], J.ldp), gsum[i]);
-                    }
-                }
-                // 16-B stores of the launch's ~4 MB of new state go out write-through (sc1): plain stores would sit dirty
-                // in the L2s until the end-of-kernel write-back, in front of the next launch
-                st4_sc1(J.PT + ot[o], p4[o]);
-                st4_sc1(J.MT + ot[o], m4[o]);
-                st4_sc1(J.VT + ot[o], v4[o]);
-            }
-            // (lanes outside the layer hold zeros: p4 was never loaded or never updated, and padding is zero by invariant)
-            float *tw = trs + wave * 256;
-            if (o > 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tw[(4 * g + i) * 16 + r] = p4[o][i];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const f32x4 pf = ld4(tw + r * 16 + 4 * g);                      // this lane as (c', g') of the forward copy
-            st4_sc1(J.P + pblk[o], pf);
-            if (polyak) st4_sc1(J.TP + pblk[o], tp4[o] * (1.0f - d.tau) + pf * d.tau);
-        }
-        if (bias_lane) {
-            const int n = n0 + threadIdx.x;
-            const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
-            adam_update(pb, mbv, vbv, gb, step_size, bc2s);
-            st1g(J.bias + n, pb); st1g(J.mb + n, mbv); st1g(J.vb + n, vbv);
-            if (J.gb && keep_grad) st1g(J.gb + n, gb);
-            if (polyak) st1g(J.Tbias + n, tbv * (1.0f - d.tau) + pb * d.tau);
-        }
-    }
-}
-
 // The body of the weight-gradient / Adam launch for virtual block `vblock` (0: the step's diagnostics; 1 .. njobs: tile
 // owners).  (A function of its own since the one-launch experiment -- this body as a phase D of k_abc behind a grid-wide
 // counter hand-off: the hand-off took 6.5 us against ~3 us for the dispatch boundary plus start-up it replaced, DESIGN.md
@@ -1593,14 +1419,143 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
         { unsigned long long probe = ud.w[0]; asm volatile("" :: "s"(probe)); }
         STAMP(4, 3);
 #endif
-        // a job = one 16-row tile of dW x a strip of up to MT 16-column tiles: four for most layers; the whole row of a
-        // first layer with 65-112 input columns (five to seven tiles: J.nt) -- its second 64-column strip used to be a job
-        // of its own, which put those shapes at more jobs than CUs (two rounds of the launch)
-        // (one instance per tile count: a five-tile row run on the seven-tile body would issue 40 % more MFMAs than it needs)
-        if (J.nt == 4) dw_tile_job<4>(d, J, S, sa, red, redb, trs, jb, aborted);
-        else if (J.nt == 5) dw_tile_job<5>(d, J, S, sa, red, redb, trs, jb, aborted);
-        else if (J.nt == 6) dw_tile_job<6>(d, J, S, sa, red, redb, trs, jb, aborted);
-        else dw_tile_job<7>(d, J, S, sa, red, redb, trs, jb, aborted);
+        const int jj = jb - J.job0;
+        const int n0 = 16 * (jj / J.nk), k0 = J.k_base + 64 * (jj % J.nk);
+        // owner of tile t == wave: lane (c = r, g) holds rows n0+4g+i, col k0 + 16*wave + c
+        const int k_own = k0 + 16 * wave + r;
+        const bool own_valid = k_own < J.K;
+        const size_t ot = frag_off(k_own, n0 + 4 * g, J.ldt);    // this lane's 16 B of the transposed copy / Adam moments
+        // dY^T and X^T are fragment-major [feature][batch]: feature tile f, batch chunk q = 1 KB at ((f * B/16) + q) * 256
+        const size_t tile_floats = (size_t)(B >> 4) * 256;
+        const float *XT = (J.xt_from_slot ? S + J.xt_off : J.XT) + (size_t)(k0 >> 4) * tile_floats;
+        const float *YT = J.dYT + (size_t)(n0 >> 4) * tile_floats;
+        const int per = (B / 16) / 4;                 // 16-row chunks of the batch per wave
+        const int rem = (B / 16) - 4 * per;
+        const int s0 = wave * per + (wave < rem ? wave : rem);
+        const int s1 = s0 + per + (wave < rem ? 1 : 0);
+        const float *yp = YT + 4 * lane;              // this lane's 16 B of a fragment: (feature r, batch rows 4g..4g+3)
+        const float *xp = XT + 4 * lane;
+        f32x4 acc[4] = {};
+        float bsum = 0.f;
+        // first group of operand loads, then the owner's state, then the scalars: all in flight together.
+        // Loads are unconditional (clamped chunk index, select on the loaded VALUE): a conditional load
+        // becomes a branch whose merge point needs the data, i.e. a vmcnt(0) right behind the load.
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto chunk_of = [&](int sq) { const int m = (sq < s1 - 1) ? sq : s1 - 1; return m > 0 ? m : 0; };
+        // k tiles of this strip that lie inside the layer (a first layer of 80 input columns has a second strip with ONE):
+        // a padding tile re-reads the last valid one -- lines that are in flight anyway -- instead of streaming 16 KB of
+        // zero (or foreign) rows; its products are never used (tile_ok below)
+        int nv = (J.ldp - k0) >> 4;
+        nv = nv > 4 ? 4 : (nv < 1 ? 1 : nv);
+        size_t toff[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) toff[t] = (size_t)(t < nv ? t : nv - 1) * tile_floats;
+        f32x4 a[4], b[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cq = chunk_of(s0 + u);
+            a[u] = ld4(yp + 256 * cq);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
+        }
+        f32x4 p4 = {0.f, 0.f, 0.f, 0.f}, m4 = p4, v4 = p4;
+        if (own_valid) {
+            p4 = ld4(J.PT + ot);
+            m4 = ld4(J.MT + ot);
+            v4 = ld4(J.VT + ot);
+        }
+        const double bc1 = sa.bc1, bc2sd = sa.bc2s;
+        const bool polyak = (J.TP != nullptr) && (sa.step_now % d.period == 0);
+        // The forward copy P [n][k] (and the Polyak target, same layout) holds this wave's 16 x 16 tile as ONE contiguous
+        // 1-KB block, lane (c', g') = (n0 + c', k 4g'..4g'+3): written below with one 16-B store per lane after a
+        // transpose through LDS (four 4-B stores + four 4-B target loads per lane before: the launch ends when its stores
+        // have drained).
+        const bool tile_ok = (k0 + 16 * wave) < J.ldp;                     // (wave-uniform: the last k tile of a 48-wide layer)
+        const size_t pblk = frag_off(n0, k0 + 16 * wave, J.ldp) + 4 * lane;
+        f32x4 tp4 = {0.f, 0.f, 0.f, 0.f};
+        if (polyak && tile_ok) tp4 = ld4(J.TP + pblk);
+        float pb = 0.f, mbv = 0.f, vbv = 0.f, tbv = 0.f;
+        const bool bias_lane = (k0 == 0) && threadIdx.x < 16 && (n0 + (int)threadIdx.x) < J.N;
+        if (bias_lane) {
+            const int n = n0 + threadIdx.x;
+            pb = ld1g(J.bias + n); mbv = ld1g(J.mb + n); vbv = ld1g(J.vb + n);
+            if (polyak) tbv = ld1g(J.Tbias + n);
+        }
+#ifdef SAC_STAMPS
+        { float probe = a[0][0] + b[3][3][3]; asm volatile("" :: "v"(probe)); }
+        STAMP(4, 4);
+#endif
+        for (int sI = s0; sI < s1; sI += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 au = (sI + u < s1) ? a[u] : zero4;
+                bsum += (au[0] + au[1]) + (au[2] + au[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(au[i], b[u][t][i], acc[t], 0, 0, 0);
+                }
+            }
+            if (sI + 4 < s1) {                       // batches above 256 rows: next group
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cq = chunk_of(sI + 4 + u);
+                    a[u] = ld4(yp + 256 * cq);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[u][t] = ld4(xp + toff[t] + 256 * cq);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st4(red + ((wave * 4 + t) * 64 + lane) * 4, acc[t]);
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (g == 0) redb[wave * 16 + r] = bsum;
+        lds_barrier();
+        STAMP(4, 1);
+        const float step_size = (float)((double)J.lr / bc1), bc2s = (float)bc2sd;
+        if (aborted) return;
+        if (tile_ok) {
+            f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) gsum += ld4(red + ((w * 4 + wave) * 64 + lane) * 4);
+            if (own_valid) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = n0 + 4 * g + i;
+                    if (n < J.N) {
+                        float p = p4[i], m = m4[i], v = v4[i];
+                        adam_update(p, m, v, gsum[i], step_size, bc2s);
+                        p4[i] = p; m4[i] = m; v4[i] = v;
+                        if (J.G && keep_grad) st1g(J.G + frag_off(n, k_own, J.ldp), gsum[i]);
+                    }
+                }
+                // 16-B stores of the launch's ~4 MB of new state go out write-through (sc1): plain stores would sit dirty
+                // in the L2s until the end-of-kernel write-back, in front of the next launch
+                st4_sc1(J.PT + ot, p4);
+                st4_sc1(J.MT + ot, m4);
+                st4_sc1(J.VT + ot, v4);
+            }
+            // (lanes outside the layer hold zeros: p4 was never loaded or never updated, and padding is zero by invariant)
+            float *tw = trs + wave * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tw[(4 * g + i) * 16 + r] = p4[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const f32x4 pf = ld4(tw + r * 16 + 4 * g);                      // this lane as (c', g') of the forward copy
+            st4_sc1(J.P + pblk, pf);
+            if (polyak) st4_sc1(J.TP + pblk, tp4 * (1.0f - d.tau) + pf * d.tau);
+        }
+        if (bias_lane) {
+            const int n = n0 + threadIdx.x;
+            const float gb = (redb[threadIdx.x] + redb[16 + threadIdx.x]) + (redb[32 + threadIdx.x] + redb[48 + threadIdx.x]);
+            adam_update(pb, mbv, vbv, gb, step_size, bc2s);
+            st1g(J.bias + n, pb); st1g(J.mb + n, mbv); st1g(J.vb + n, vbv);
+            if (J.gb && keep_grad) st1g(J.gb + n, gb);
+            if (polyak) st1g(J.Tbias + n, tbv * (1.0f - d.tau) + pb * d.tau);
+        }
         STAMP(4 - 2 * (sa.loop_pos & 1), 2);
     } else if (aborted) {
         // tell the host which launch was the first one not applied (diagnostic slots 30 / 31 are unused)
@@ -1728,7 +1683,7 @@ __device__ __forceinline__ void dw_adam_body(const Dev &d, const DwTable &T, con
 
 __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *__restrict__ S, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + sizeof(DwTable) + 8 + sizeof(StepArg)>();
-    __shared__ __attribute__((aligned(16))) float red[4 * 7 * 64 * 4];   // 28 KB: [wave][tile <= 7][lane][4] (also diag scratch)
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];   // 16 KB (also diag scratch)
     __shared__ __attribute__((aligned(16))) float redb[4 * 16 * 2];
     __shared__ __attribute__((aligned(16))) float trs[4 * 256];           // a wave's 16 x 16 tile on its way to the forward copy
     // fused step: the forward/backward launch gave up (a hand-off wait timed out) => this launch, the step's only
@@ -2270,9 +2225,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
             Net &n = t->net[netid];
             const Layer &L = n.L[l];
             const int nk_all = (L.Kp + 63) / 64;
-            // a first layer of 65-112 input columns: ONE job per row tile (5-7 tiles); wider ones keep 64-column strips + a tail
-            const bool whole_row = (l == 0) && L.Kp > 64 && L.Kp <= 112 && !getenv("SAC_DW_NO_MERGE");
-            const bool has_tail = (l == 0) && (L.Kp % 64 != 0) && nk_all > 1 && !whole_row;
+            const bool has_tail = (l == 0) && (L.Kp % 64 != 0) && nk_all > 1;
             if (part == 1 && !has_tail) return;
             T.job0[nl++] = job;
             hl.emplace_back();
@@ -2288,9 +2241,8 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
                 J.Tbias = t->net[tgt].P + L.offB;
             }
             J.ldp = L.Kp; J.ldt = L.Np; J.N = L.N; J.K = L.K; J.lr = lr;
-            J.nk = whole_row ? 1 : ((part == 1) ? 1 : (has_tail ? nk_all - 1 : nk_all));
-            J.k_base = (part == 1) ? 64 * (nk_all - 1) : 0;
-            J.nt = whole_row ? L.Kp / 16 : 4;
+            J.nk = (part == 1) ? 1 : (has_tail ? nk_all - 1 : nk_all);
+            J.k_base = (part == 1) ? 64 * (nk_all - 1) : 0; J.pad_ = 0;
             J.job0 = job;
             job += (L.Np / 16) * J.nk;
         };
