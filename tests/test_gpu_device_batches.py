@@ -214,3 +214,92 @@ def test_a_buffer_outlives_the_trainer_whose_stream_it_remembered():
             assert np.array_equal(x["params"][k], y["params"][k]), k
         assert np.array_equal(x["scalars"], y["scalars"])
     assert ra[1] == rb[1] and np.array_equal(ra[0], rb[0])
+
+
+def test_bound_to_np_random_under_any_interleaving():
+    """The construction default: the buffer samples np.random ITSELF (bound to its state words).  Whatever happens in
+    between -- host consumers of np.random (env resets, exploration noise), np.random.seed / set_state, inserts, other batch
+    sizes, host batches, bare index draws, fused loops, reading the state through the buffer -- every batch is what
+    np.random.randint would have drawn at that point, np.random is where rlkit would have left it after EVERY call, and the
+    read-ahead never leaks a speculative draw into it."""
+    O, A, cap = 9, 3, 20000
+    rs_data = np.random.RandomState(5)
+    obs = rs_data.normal(size=(cap, O)).astype(np.float32)
+    act = rs_data.uniform(-1, 1, (cap, A)).astype(np.float32)
+    rew = rs_data.uniform(0, 1, (cap, 1)).astype(np.float32)
+    nobs = rs_data.normal(size=(cap, O)).astype(np.float32)
+    term = np.zeros((cap, 1), np.uint8)
+    buf = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)                  # (numpy_global_stream=True is the default)
+    assert buf._bound
+    size = 3000
+    buf.add_block(obs[:size], act[:size], rew[:size], nobs[:size], term[:size])
+    np.random.seed(99)
+    ref = np.random.RandomState(99)                                      # what np.random must look like at every point
+    _, tr = make_pair(O, A, 48, seed=2)
+    script = np.random.RandomState(7)
+    pending = []
+
+    def same_state():
+        a, b = np.random.get_state(), ref.get_state()
+        assert a[2] == b[2] and np.array_equal(a[1], b[1]) and a[3] == b[3] and a[4] == b[4]
+
+    def check(db, want):
+        assert np.array_equal(db.indices(), want)
+        assert np.array_equal(db["observations"], obs[want]) and np.array_equal(db["rewards"], rew[want])
+
+    for it in range(500):
+        r = script.randint(0, 100)
+        if r < 62:                                           # the common case: the next batch
+            B = 48 if r < 56 else 33
+            if pending and pending[-1][0]._batch_size != B:
+                while pending:
+                    check(*pending.pop(0))
+            pending.append((buf.random_batch(B), ref.randint(0, size, B)))
+        elif r < 70:                                         # a host consumer: an env reset, exploration noise (gauss cache too)
+            k = int(script.randint(1, 9))
+            assert np.array_equal(np.random.normal(size=k), ref.normal(size=k))
+        elif r < 74:
+            assert np.array_equal(np.random.randint(0, 1000, 5), ref.randint(0, 1000, 5))
+        elif r < 80:                                         # an insert
+            n = int(script.randint(1, 40))
+            buf.add_block(obs[size:size + n], act[size:size + n], rew[size:size + n], nobs[size:size + n], term[size:size + n])
+            size += n
+        elif r < 83:                                         # the state through the buffer (no device round trip when bound)
+            key, pos = buf.rng_state()
+            st = ref.get_state()
+            assert pos == st[2] and np.array_equal(key, st[1])
+        elif r < 86:                                         # somebody re-seeds / restores np.random
+            s = int(script.randint(0, 1 << 30))
+            if s & 1:
+                np.random.seed(s); ref.seed(s)
+            else:
+                st = np.random.RandomState(s).get_state()
+                np.random.set_state(st); ref.set_state(st)
+        elif r < 91:                                         # a host batch
+            b, idx = buf.random_batch(20, return_indices=True)
+            want = ref.randint(0, size, 20)
+            assert np.array_equal(idx, want) and np.array_equal(b["actions"], act[want])
+        elif r < 95:                                         # bare index draws
+            got = buf.sample_indices(17, 3)
+            for k in range(3):
+                assert np.array_equal(got[k], ref.randint(0, size, 17))
+        else:                                                # a fused loop
+            tr.train_loop(buf, 3, batch_size=48)
+            for _ in range(3):
+                ref.randint(0, size, 48)
+        same_state()                                         # after EVERY call, without any hand-over
+        while len(pending) > 12 or (pending and script.randint(0, 4) == 0):
+            check(*pending.pop(0))
+    for p in pending:
+        check(*p)
+    # leaving and rejoining the global stream
+    buf.seed(5)
+    assert not buf._bound
+    state = np.random.get_state()
+    private = np.random.RandomState(5)
+    assert np.array_equal(buf.random_batch(32).indices(), private.randint(0, size, 32))
+    assert np.array_equal(np.random.get_state()[1], state[1])           # np.random untouched by a private stream
+    buf.bind_numpy_global_stream()
+    ref.set_state(np.random.get_state())
+    assert np.array_equal(buf.random_batch(32).indices(), ref.randint(0, size, 32))
+    same_state()
