@@ -255,7 +255,8 @@ def td3_main(args):
                higher_is_better=True, vs_baseline=None, dtype="f32", data="synthetic (as the SAC line)",
                config=dict(workload=f"Lift-Panda TD3 inner loop: obs {O} / act {A}, batch {B}, {args.buffer}-slot HBM replay "
                                     "buffer, hidden 256x256, policy_and_target_update_period 2, tau .005, noise .2 / clip .5"),
-               launches_per_step="4 (critic pass) + 3 on policy steps",
+               launches_per_step=("2 (critic pass: k_abc<M_TD3_CRITIC> + k_dw_adam)" if tr.is_fused() else "4 (critic pass)")
+               + " + 3 on policy steps",
                roofline=dict(bound="mfma", unit="TFLOP/s", peak=PEAK_FP32_MFMA_TFLOPS, gflop_per_step=round(gflop, 4),
                              achieved=round(gflop * args.steps / el / 1e3, 3),
                              frac=round(gflop * args.steps / el / 1e3 / PEAK_FP32_MFMA_TFLOPS, 5), traffic=None),

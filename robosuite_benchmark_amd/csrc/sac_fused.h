@@ -130,7 +130,12 @@ __device__ __forceinline__ bool split_first_layer(WRing<1, D> &rq, const float *
     return true;
 }
 
-template <int NTH, bool WIDE>
+// MODE M_TD3_CRITIC (round 3): the TD3 critic pass as the same launch.  Critic chain: phase A (Q_i(s, a)), no phase B, phase C
+// (critic backward, target without entropy term) behind the target partials.  Policy chain on s' (net 1): the TARGET
+// policy, head = tanh(mean) + clipped smoothing noise, T2; policy chain on s (net 0): the online policy's phase A only when
+// an actor pass follows this launch (sa.pad2 bit 2: its head partials and activations are what that pass reads), then T1.
+// No log pi anywhere, no policy backward (the actor pass keeps its own launches).
+template <int NTH, bool WIDE, int MODE = M_SAC>
 __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     constexpr int SP = 4, SW = 64;
@@ -176,8 +181,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     f32x4 keep1[4], zkeep[4];
     float bv1[1], w3[4];
     unsigned peek = 0u;                  // (thread 0 of a critic-chain block: early look at head[s][rb])
-    {
-        const float *P = isq ? d.P[1 + net] : d.P[0];
+    // TD3 critic pass: the online policy on s runs only when an actor pass follows (it reads this chain's head partials)
+    const bool skip_a = (MODE == M_TD3_CRITIC) && !isq && net == 0 && !(sa.pad2 & 4u);
+    if (!skip_a) {
+        const float *P = isq ? d.P[1 + net] : ((MODE == M_TD3_CRITIC && net == 1) ? d.P[5] : d.P[0]);
         const Layer L0 = isq ? d.LQ[0] : d.LP[0], L1 = isq ? d.LQ[1] : d.LP[1], L2 = isq ? d.LQ[2] : d.LP[2];
         const int K0 = isq ? d.KQ : d.KP;
         const float *obs = S + ((!isq && net) ? SL.off_nobs : SL.off_obs) + (size_t)row0 * O;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         } else {        // partial Q_i(s, a) over these 64 columns
             // (early look at the head counter of phase B: the policy chains publish ~1 us before this chain gets here, so the
             //  wait below usually finds this answer waiting and costs no round trip)
-            if (threadIdx.x == 0) peek = __hip_atomic_load(cnt_head + (size_t)rb * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MODE == M_SAC && threadIdx.x == 0) peek = __hip_atomic_load(cnt_head + (size_t)rb * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float s = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) s += XS[lds_off(row, a + 16 * u, SW)] * w3[u];
@@ -277,12 +284,20 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             if (a == 0) st_sc1(d.qpart2 + ((size_t)(net * NB + rb) * SP + part) * 32 + row, s);
         }
     }
+    if (skip_a) {
+        // (what phase A would have left for phase B: the noise draw; and the exchange counter of this chain's split first
+        //  layer keeps in step with the launch number -- counters count in units of it)
+        if (a < A && !d.eps2) eps = philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(grow * 16 + a), 1u);
+        if (WIDE && threadIdx.x == 0) __hip_atomic_fetch_add(cnt_zx + (size_t)(2 * NB + rb) * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     STAMP(0, 1);
     // (the critic chain's phase-A results -- q partial, h2 slice -- are read by its siblings' backward phase: it signals
     //  them behind the head wait below, when their stores have long left, instead of draining them here)
-    if (!isq) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
+    if (!isq && !skip_a) handoff_publish(cnt_head + (size_t)(net * NB + rb) * CNT_STRIDE);
+    // (TD3 critic pass: the critic chain has no phase B; its phase-A results are signalled to its siblings' backward here)
+    if (MODE == M_TD3_CRITIC && isq) handoff_publish(cnt_qa + (size_t)rb * CNT_STRIDE);
     STAMP(0, 2);
-    if (!isq && net == 0) {             // pi(s)'s activations for the weight-gradient launch and the policy backward (ordered by tq)
+    if (!isq && net == 0 && !skip_a) {  // pi(s)'s activations for the weight-gradient launch and the policy backward (ordered by tq)
         if (wave == part) store_features<4, true>(keep1, 64 * wave, 16, d.PH1T, B, row0);
         f32x4 v;
 #pragma unroll
@@ -293,6 +308,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // =========================================================================================================
     // phase B: requests that do not depend on the hand-off first, then the wait
     // =========================================================================================================
+    WRing<1, 8> rc;                      // critic chain: the transposed W2 slice of the critic backward (phase C)
+    if (MODE == M_SAC || !isq) {         // (TD3 critic pass: the critic chain goes straight on to phase C)
     const int p4 = isq ? net : 2 + net;                       // Q1, Q2 on (s, a_new) | T1, T2 on (s', a')
     const int side = isq ? 0 : 1, pass = 2 + p4;
     const float *PQ = d.P[1 + p4];
@@ -302,7 +319,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // they have: +1-2 us), and only then the weight requests -- they land under the head math.
     const float *epp = side ? d.eps2 : d.eps1;
     const int am = (a < A) ? a : 0;
-    const float hbm = d.P[0][d.LP[2].offB + am], hbr = d.P[0][d.LP[2].offB + A + am];
+    const float *PH = (MODE == M_TD3_CRITIC) ? d.P[5] : d.P[0];       // head bias: target policy / online policy
+    const float hbm = PH[d.LP[2].offB + am], hbr = (MODE == M_SAC) ? PH[d.LP[2].offB + A + am] : 0.f;
     if (a < A && epp) eps = epp[grow * A + am];            // (caller-supplied noise; the device stream's draw was made at entry)
     // (a handful of small loads that do not depend on the hand-off either: the s' rows of the target net / the batch action)
     RowRegs<WIDE ? 32 : 8> rows2;
@@ -320,7 +338,10 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     {
         const float *hp = d.headpart + (size_t)(side * NB + rb) * SP * (RB * 32) + row * 32;
 #pragma unroll
-        for (int p = 0; p < SP; ++p) { hm[p] = ld_sc1(hp + p * (RB * 32) + am); hr[p] = ld_sc1(hp + p * (RB * 32) + A + am); }
+        for (int p = 0; p < SP; ++p) {
+            hm[p] = ld_sc1(hp + p * (RB * 32) + am);
+            hr[p] = (MODE == M_SAC) ? ld_sc1(hp + p * (RB * 32) + A + am) : 0.f;      // (TD3 heads have no log-std rows)
+        }
     }
     f32x4 acc0[4];
     float bv0b[4];
@@ -373,14 +394,20 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
 #pragma unroll
         for (int p = 1; p < SP; ++p) { mean += hm[p]; raw += hr[p]; }     // fixed order
         mean += hbm; raw += hbr;
-        lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        stdv = expf(lstd);
-        zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                  // TanhNormal.rsample
-        act = tanhf(zz);
-        const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
-        const float var = __fmul_rn(stdv, stdv);
-        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
-        lp = nlp - logf(1.0f - act * act + TANH_EPS);
+        if constexpr (MODE == M_SAC) {
+            lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+            stdv = expf(lstd);
+            zz = __fadd_rn(mean, __fmul_rn(stdv, eps));                  // TanhNormal.rsample
+            act = tanhf(zz);
+            const float dd = __fsub_rn(zz, mean);                            // Normal.log_prob(z)
+            const float var = __fmul_rn(stdv, stdv);
+            const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+            lp = nlp - logf(1.0f - act * act + TANH_EPS);
+        } else {
+            // TD3 target smoothing (k_fwd_b<M_TD3_CRITIC>): a' + clamp(N(0,1) * sigma, +-clip); the sum is NOT re-clipped
+            zz = tanhf(mean);
+            act = zz + fminf(fmaxf(eps * d.td3_sigma, -d.td3_clip), d.td3_clip);
+        }
     }
     // the whole action chunk (0 beyond A); the critic chain contracts the difference to the batch action
     X0[lds_off(row, d.KP + a, KLQ)] = (a < A) ? (isq ? act - abat : act) : 0.f;
@@ -436,7 +463,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             if (threadIdx.x == 0) st_sc1(d.part_logpi + rb, lsum_blk);
         } else if (own_n) {
             d.a2[grow * 16 + a] = act;
-            if (a == 0) { d.logpi2[grow] = lsum; st_sc1(d.logpi2p + rb * 32 + row, lsum); }
+            if (MODE == M_SAC && a == 0) { d.logpi2[grow] = lsum; st_sc1(d.logpi2p + rb * 32 + row, lsum); }
         }
         slice_epilogue<1>(acc, bv1, wave, XS, nullptr, n0, B, row0);
     }
@@ -455,7 +482,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     }
     // critic chain: the transposed W2 slice of the critic backward (phase C) is requested HERE, in front of the actor
     // tail -- it depends on no hand-off, and its first eight k-chunks land while the tail runs
-    WRing<1, 8> rc;
     if (isq) {
         rc.init(d.PT[1 + net] + d.LQ[1].offWt, H, n0, 16);
         rc.fill(H >> 4);
@@ -490,6 +516,12 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     STAMP(0, 6);
     handoff_publish((isq ? cnt_ac : cnt_tq) + (size_t)rb * CNT_STRIDE);
     STAMP(0, 7);
+    }   // phase B
+    if (MODE == M_TD3_CRITIC) {
+        if (!isq) return;                // (the policy chains of a TD3 critic pass have no backward)
+        rc.init(d.PT[1 + net] + d.LQ[1].offWt, H, n0, 16);
+        rc.fill(H >> 4);
+    }
 
     // =========================================================================================================
     // phase C.  Critic chain: critic backward of Q_i as soon as the TARGET partials of the row-block are out (it does
@@ -506,7 +538,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const int k = threadIdx.x;
         // the three counters in ONE round trip, with nothing of this block in flight; the target partials have usually been
         // out for a microsecond by now (the policy chains have no actor tail)
-        handoff_wait_multi(3, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp,
+        handoff_wait_multi((MODE == M_SAC) ? 3 : 2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp,
                            (unsigned)NB * seq, d.abort_flag, &s_ok);
         lds_barrier();
         if (!s_ok) return;
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
                 qb[p] = ld_sc1(d.qpart2 + ((size_t)(5 * NB + rb) * SP + p) * 32 + threadIdx.x);
                 qq[p] = ld_sc1(d.qpart2 + ((size_t)(net * NB + rb) * SP + p) * 32 + threadIdx.x);
             }
-            in_c = ld_sc1(d.logpi2p + rb * 32 + threadIdx.x);
+            if constexpr (MODE == M_SAC) in_c = ld_sc1(d.logpi2p + rb * 32 + threadIdx.x);
             in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
         }
         f32x4 h2v[4];
@@ -532,7 +564,9 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         for (int qd = 0; qd < 4; ++qd) h2v[qd] = ld4(h2T + frag_off(k, row0 + 4 * qd, B));
         f32x4 h1v[1];
         h1v[0] = ld4(h1T + frag_off(n0 + c, row0 + 4 * g, B));
-        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        float alpha = 0.f;                                                   // (TD3: no entropy term in the target)
+        if constexpr (MODE == M_SAC)
+            alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
         if (threadIdx.x < RB) {
             va = qa[0]; vb = qb[0]; vq = qq[0];

@@ -1861,6 +1861,27 @@ int ensure_stage_t(sac_trainer *t, size_t bytes) {
 // targets and the actor pass follows -- Q1(s, policy(s)) through the ALREADY UPDATED qf1, policy backward, policy
 // Adam + soft update of the target policy.  want_stats: also produce Policy Loss / Policy Action on a non-policy
 // step (rlkit recomputes them for the epoch statistics), without any update.
+// Fused launches of different trainers (streams) of one process must not overlap on a device: two half-resident grids
+// would wait for each other's CUs until the hand-off timeout.  While more than one fused trainer lives on a device,
+// each fused launch waits for the previous one there and records an event behind itself (host section under a lock).
+struct FusedGate { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; int live = 0; };
+FusedGate g_gate[64];
+
+// the fused forward/backward launch of a step (k_abc: SAC, or the TD3 critic pass); sa gets the launch number
+int launch_fused_abc(sac_trainer *t, const float *S, const SlotLayout &SL, StepArg &sa, unsigned extra_flags) {
+    hipStream_t s = t->stream;
+    sa.seq = ++t->fused_seq;
+    sa.pad2 |= extra_flags | ((t->test_stall_at && sa.seq == t->test_stall_at) ? 1u : 0u);
+    t->fused_unchecked += 1;
+    FusedGate &G = g_gate[t->device & 63];
+    std::lock_guard<std::mutex> lk(G.mu);
+    const bool gate = G.live > 1 && !t->gate_exempt;
+    if (gate && G.last && G.last != s) SAC_HIP(hipStreamWaitEvent(s, G.ev, 0));
+    hipLaunchKernelGGL(t->abc, dim3(16 * t->NB), dim3(256), t->lds_abc, s, t->dev, S, SL, sa);
+    if (gate) { SAC_HIP(hipEventRecord(G.ev, s)); G.last = s; }
+    return 0;
+}
+
 int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j, bool want_stats) {
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
@@ -1873,9 +1894,14 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
     // (the diagnostics -- and the flat gradient copies of sac_debug_fetch -- go out only on the steps whose caller reads
     //  them, like the SAC step's; td3_diagnostics keeps "last" the most recent value of each entry across launches)
     sq.pad2 = sp.pad2 = t->publish_diag ? 2u : 0u;
-    hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
-    hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
-    hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
+    if (t->fused) {
+        // the critic pass as ONE launch (k_abc<.., M_TD3_CRITIC>, sac_fused.h) + its weight-gradient launch
+        if (launch_fused_abc(t, S, SL, sq, actor ? 4u : 0u)) return -1;
+    } else {
+        hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
+        hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
+        hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
+    }
     const DwTable &Tq = pstep ? t->dw_q_tp : t->dw_q;
     hipLaunchKernelGGL(k_dw_adam, dim3(Tq.njobs + 1), dim3(256), 0, s, d, Tq, S, sq);
     if (actor) {
@@ -1896,11 +1922,6 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
 
 // the four launches of step j of the current chunk, on minibatch slot S; ev != null => HIP events
 // between the launches (profiling pass only)
-// Fused launches of different trainers (streams) of one process must not overlap on a device: two half-resident grids
-// would wait for each other's CUs until the hand-off timeout.  While more than one fused trainer lives on a device,
-// each fused launch waits for the previous one there and records an event behind itself (host section under a lock).
-struct FusedGate { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; int live = 0; };
-FusedGate g_gate[64];
 
 int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr, bool want_stats = false) {
     if (t->algo == 1) return launch_step_td3(t, S, SL, j, want_stats);
@@ -1914,17 +1935,7 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
     if (ev) SAC_HIP(hipEventRecord(ev[0], s));
     if (t->fused) {
         // two launches: A + B + C as k_abc (in-launch hand-offs), then the weight-gradient / Adam launch
-        sa.seq = ++t->fused_seq;
-        sa.pad2 |= (t->test_stall_at && sa.seq == t->test_stall_at) ? 1u : 0u;
-        t->fused_unchecked += 1;
-        FusedGate &G = g_gate[t->device & 63];
-        {
-            std::lock_guard<std::mutex> lk(G.mu);
-            const bool gate = G.live > 1 && !t->gate_exempt;
-            if (gate && G.last && G.last != s) SAC_HIP(hipStreamWaitEvent(s, G.ev, 0));
-            hipLaunchKernelGGL(t->abc, dim3(16 * NB), dim3(256), t->lds_abc, s, d, S, SL, sa);
-            if (gate) { SAC_HIP(hipEventRecord(G.ev, s)); G.last = s; }
-        }
+        if (launch_fused_abc(t, S, SL, sa, 0u)) return -1;
         if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); SAC_HIP(hipEventRecord(ev[3], s)); }
     } else {
         if (t->chain) {
@@ -1963,6 +1974,11 @@ static int wait_trainer_stream(sac_trainer *t, hipEvent_t recorded = nullptr) {
     return 0;
 }
 
+// every weight-gradient table of the trainer looks at (or stops looking at) the fused step's give-up word
+static void set_abort_ptrs(sac_trainer *t, const unsigned *p) {
+    t->dw.abort = p; t->dw_q.abort = p; t->dw_q_tp.abort = p; t->dw_pi.abort = p; t->dw_none.abort = p;
+}
+
 // wait for ONE event (not for the stream behind it): a short user-space poll, then the blocking wait
 static int wait_event(hipEvent_t e) {
     const auto spin_until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
@@ -1992,7 +2008,11 @@ int check_fused_abort(sac_trainer *t, unsigned *lost_out = nullptr) {
     t->n_train_steps_total -= lost;
     t->adam_t -= lost;
     t->fused = false;
-    t->dw.abort = nullptr;
+    set_abort_ptrs(t, nullptr);
+    if (t->algo == 1) {          // TD3: the policy's optimizer steps among the lost steps (every td3_period-th step number)
+        for (long long k = t->n_train_steps_total; k < t->n_train_steps_total + (long long)lost; ++k)
+            if (k % t->td3_period == 0) t->adam_t_pi -= 1;
+    }
     t->h_diag[SAC_DIAG_N + 30] = t->h_diag[SAC_DIAG_N + 31] = 0.f;
     SAC_HIP(hipMemsetAsync(t->d_sync, 0, t->sync_bytes, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
@@ -2315,13 +2335,14 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
         const char *e = getenv("SAC_FUSED");
         t->lds_abc = sizeof(float) * (size_t)(RB * KL0q + RB * H + RB * 64 + FUSED_RED + H * WLD);
-        t->fused = !td3 && t->SP == 4 && t->NB <= 16 && 16 * t->NB <= cus && t->lds_abc <= 160 * 1024 - 512 && !(e && atoi(e) == 0);
+        t->fused = t->SP == 4 && t->NB <= 16 && 16 * t->NB <= cus && t->lds_abc <= 160 * 1024 - 512 && !(e && atoi(e) == 0);
         if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
-        t->abc = (nth == 1) ? (wide ? &k_abc<1, true> : &k_abc<1, false>) : (wide ? &k_abc<2, true> : &k_abc<2, false>);
+        if (td3) t->abc = wide ? &k_abc<1, true, M_TD3_CRITIC> : &k_abc<1, false, M_TD3_CRITIC>;
+        else t->abc = (nth == 1) ? (wide ? &k_abc<1, true> : &k_abc<1, false>) : (wide ? &k_abc<2, true> : &k_abc<2, false>);
         if (t->fused) {
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->abc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)t->lds_abc));
-            t->dw.abort = d.abort_flag;
+            set_abort_ptrs(t, d.abort_flag);
             FusedGate &G = g_gate[t->device & 63];
             std::lock_guard<std::mutex> lk(G.mu);
             if (!G.ev) SAC_HIP(hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
@@ -2901,7 +2922,7 @@ int sac_trainer_set_xcd_mask(sac_trainer_t *t, unsigned xcd_mask) {
         } else {
             t->gate_exempt = false;
             t->fused = false;
-            t->dw.abort = nullptr;
+            set_abort_ptrs(t, nullptr);
         }
     }
     return 0;

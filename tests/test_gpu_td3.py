@@ -139,3 +139,92 @@ def test_td3_variant_through_the_driver_with_checkpoint_resume(tmp_path):
     for k in straight[2]:
         if not k.startswith("time/"):
             assert straight[2][k] == resumed[0][k], k
+
+
+# ---- round 3: the TD3 critic pass as ONE launch (k_abc<.., M_TD3_CRITIC>, csrc/sac_fused.h) ----------------------------
+def _td3_pair_of_hip(O, A, B, seed, noise_seed, **env):
+    """(fused critic pass, four-launch critic pass) TD3 trainers with identical parameters."""
+    import os
+    old = {k: os.environ.get(k) for k in ("SAC_FUSED", "SAC_FUSED_TEST_STALL")}
+    try:
+        os.environ.pop("SAC_FUSED", None)
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        _, fused = make_td3_pair(O, A, B, seed=seed, noise_seed=noise_seed)
+        os.environ.pop("SAC_FUSED_TEST_STALL", None)
+        os.environ["SAC_FUSED"] = "0"
+        _, plain = make_td3_pair(O, A, B, seed=seed, noise_seed=noise_seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return fused, plain
+
+
+def _filled(n, O, A, seed):
+    obs, act, rew, term, nobs = synth_transitions(n, O, A, seed=seed, term_frac=0.05)
+    b = EnvReplayBuffer(n, obs_dim=O, action_dim=A)
+    b.add_block(obs, act, rew, nobs, term)
+    return b
+
+
+def _same_state(sa, sb):
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    for k in sa["opt"]:
+        assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
+
+
+# narrow and wide first layers, odd batches (padded row-blocks), one row-block, the largest action chunk
+@pytest.mark.parametrize("O,A,B,steps", [(42, 7, 256, 21), (42, 7, 128, 15), (89, 14, 256, 9), (379, 6, 256, 7), (10, 3, 16, 13),
+                                         (60, 7, 250, 9), (130, 16, 64, 7), (1, 1, 17, 6)])
+def test_fused_critic_pass_equals_four_launch_critic_pass_bitwise(O, A, B, steps):
+    fused, plain = _td3_pair_of_hip(O, A, B, seed=4, noise_seed=9)
+    assert fused.is_fused() and not plain.is_fused()
+    bufs = [_filled(5000, O, A, 8), _filled(5000, O, A, 8)]
+    for b in bufs:
+        b.seed(31)
+    fa, la = fused.train_loop(bufs[0], steps, batch_size=B)
+    fb, lb = plain.train_loop(bufs[1], steps, batch_size=B)
+    assert np.array_equal(fa, fb) and np.array_equal(la, lb)
+    ta = fused.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
+    tb = plain.debug_fetch("diag_trace", steps * 32).reshape(steps, 32)
+    assert np.array_equal(ta, tb)
+    _same_state(fused.state_dict(), plain.state_dict())
+    for name, n in (("q1", B), ("q2", B), ("q_target", B), ("a_next", B * A)):
+        assert np.array_equal(fused.debug_fetch(name, n), plain.debug_fetch(name, n)), name
+
+
+def test_td3_single_steps_with_given_noise_fused_vs_four_launch():
+    O, A, B = 46, 7, 256
+    fused, plain = _td3_pair_of_hip(O, A, B, seed=2, noise_seed=1)
+    for step in range(5):                                    # policy steps and critic-only steps alternate
+        nb, eps = batch_and_noise(B, O, A, seed=50 + step)
+        da, db = fused.train(nb, eps=eps), plain.train(nb, eps=eps)
+        fused.end_epoch(step); plain.end_epoch(step)
+        assert np.array_equal(da, db), step
+    _same_state(fused.state_dict(), plain.state_dict())
+
+
+@pytest.mark.parametrize("stall_at,steps", [(3, 10), (6, 11)])
+def test_td3_fused_pass_giving_up_falls_back_transparently(stall_at, steps):
+    """Launch `stall_at` loses a producer (test hook): that critic pass, its actor pass if it had one, and everything queued
+    behind apply nothing; the call re-runs the lost steps on the four-launch kernels.  The policy's own optimizer-step
+    count (every second step) comes back right too."""
+    O, A, B = 42, 7, 256
+    fused, plain = _td3_pair_of_hip(O, A, B, seed=4, noise_seed=9, SAC_FUSED_TEST_STALL=stall_at)
+    bufs = [_filled(4000, O, A, 8), _filled(4000, O, A, 8)]
+    for b in bufs:
+        b.seed(31)
+    fa, la = fused.train_loop(bufs[0], steps, batch_size=B)
+    assert not fused.is_fused()
+    fb, lb = plain.train_loop(bufs[1], steps, batch_size=B)
+    assert np.array_equal(fa, fb) and np.array_equal(la, lb)
+    _same_state(fused.state_dict(), plain.state_dict())
+    sc = fused.state_dict()["scalars"]
+    assert (sc[0], sc[3], sc[4]) == ((steps + 1) // 2, steps, steps)
+    (ka, pa), (kb, pb) = bufs[0].rng_state(), bufs[1].rng_state()
+    assert pa == pb and np.array_equal(ka, kb)
