@@ -240,6 +240,12 @@ int sac_step_device(sac_trainer_t *t, sac_buffer_t *buf, int64_t token, float di
  * nothing else touches np.random or the buffer inside the loop), gathered into HBM slots, then the
  * steps run back to back with no host round trip.  diag_first / diag_last (may be NULL) receive the
  * diagnostics of the first and last step (the reference logs the first step of each epoch). */
+/* Calls in a row: a call that directly follows another sac_train_loop on the same buffer (nothing in between that touches
+ * the generator, the rows or the slots) leaves the NEXT call's first four batches drawn and gathered behind its own, under
+ * its last steps, so that the next call's first step has no draw and no gather in front of it (~15 us of a call).  That
+ * chunk is speculation: the generator's state as everybody sees it (sac_rng_get_state, np.random when bound) stays behind
+ * the batches handed out, and any other entry point that comes first takes the speculation back.  Results and index
+ * stream are those of calls that never speculate, bit for bit (tests/test_gpu_train_loop.py). */
 int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *diag_first, float *diag_last);
 
 /* 1 while the trainer runs the FUSED step: launches A + B + C of the step as one launch (k_abc) whose workgroups hand

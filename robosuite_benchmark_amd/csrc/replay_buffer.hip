@@ -337,6 +337,7 @@ int ensure_idx(sac_buffer *b, int64_t n) {
 int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
     SlotLayout L = make_slot_layout(B, b->O, b->A);
     const int64_t need = L.slot_floats * n_slots;
+    if (b->spec_valid && (b->slots_cap < need || b->slot.Bt != B || !b->in_loop) && loop_spec_drop(b)) return -1;
     if (b->slots_cap < need) {
         if (b->d_slots) { SAC_HIP(hipStreamSynchronize(b->stream)); SAC_HIP(hipFree(b->d_slots)); }
         b->d_slots = nullptr;
@@ -351,6 +352,7 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
         SAC_HIP(hipMemsetAsync(b->d_slots, 0, sizeof(float) * b->slots_cap, b->stream));
         if (b->d_idx) SAC_HIP(hipMemsetAsync(b->d_idx, 0, sizeof(int64_t) * b->idx_cap, b->stream));
     }
+    if (b->slot.Bt != B || b->slot.slot_floats != L.slot_floats) b->loop_pos = 0;
     b->slot = L;
     b->n_slots = n_slots;
     return 0;
@@ -359,6 +361,8 @@ int ensure_slots(sac_buffer *b, int B, int64_t n_slots) {
 // `batch` indices per batch, stored at a stride of round_up(batch, 16).  dst == null: into b->d_idx + idx_offset
 // (idx_offset in elements of that padded layout; the buffer is grown as needed when idx_offset == 0).
 int readahead_rollback(sac_buffer *b) {
+    if (!b->in_loop) b->loop_streak = 0;         // (an outside touch: the next loop call is not "in a row")
+    if (loop_spec_drop(b)) return -1;
     b->ra_streak = 0;
     if (b->ra_ahead <= 0) return 0;
     const int consumed = b->ra_chunk - (int)b->ra_ahead;
@@ -436,11 +440,19 @@ static void readahead_drop(sac_buffer *b) {
     b->ra_ahead = 0;
 }
 
+// a speculative first chunk of the next loop call is void: the device generator goes back to the mirror
+int loop_spec_drop(sac_buffer *b) {
+    if (!b->spec_valid) return 0;
+    b->spec_valid = false;
+    return upload_rng(b, b->host_seen);
+}
+
 int host_rng_sync_in(sac_buffer *b) {
     if (!b->host_key) return 0;
     const int32_t hp = *b->host_pos;
     if (hp == b->host_seen.pos && memcmp(b->host_key, b->host_seen.mt, sizeof(uint32_t) * MT_N) == 0) return 0;
     SAC_REQUIRE(hp >= 0 && hp <= MT_N, "bound host generator holds an invalid position %d", (int)hp);
+    b->spec_valid = false; b->loop_streak = 0;   // (the generator is replaced below anyway)
     readahead_drop(b);
     memcpy(b->host_seen.mt, b->host_key, sizeof(uint32_t) * MT_N);
     b->host_seen.pos = hp;
@@ -656,6 +668,7 @@ int sac_buffer_destroy(sac_buffer_t *b) {
     if (!b) return 0;
     (void)hipSetDevice(b->device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->spec_ev) (void)hipEventDestroy(b->spec_ev);
     for (void *p : {(void *)b->obs, (void *)b->nobs, (void *)b->act, (void *)b->rew, (void *)b->term,
                     (void *)b->d_rng, (void *)b->d_idx, (void *)b->d_slots})
         (void)hipFree(p);
@@ -696,6 +709,7 @@ int sac_make_xcd_stream(hipStream_t *out, int xcd) {
 int sac_buffer_set_xcd_mask(sac_buffer_t *b, unsigned xcd_mask) {
     SAC_REQUIRE(b != nullptr, "null buffer");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;
     SAC_HIP(hipStreamSynchronize(b->stream));
     hipStream_t ns = nullptr;
     if (sac_make_xcd_mask_stream(&ns, xcd_mask)) return -1;
@@ -951,6 +965,8 @@ int sac_random_batch_device(sac_buffer_t *b, int batch, int64_t *token) {
     if (ensure_ring(b, batch)) return -1;
     SAC_REQUIRE(b->size > 0, "random_batch on an empty replay buffer");
     if (host_rng_sync_in(b)) return -1;      // (bound generator: somebody else moved np.random -> the speculation is void)
+    b->loop_streak = 0;
+    if (loop_spec_drop(b)) return -1;        // (a loop call's speculative next chunk: this draw comes first)
     const int64_t n = b->ring_next;
     const int slot = (int)(n % sac_buffer::NRING);
     if (b->ra_ahead > 0) {                   // drawn and gathered ahead by an earlier call: hand it out
@@ -1027,6 +1043,7 @@ int sac_gather(sac_buffer_t *b, const int64_t *idx, int batch, float *obs, float
                float *next_obs) {
     SAC_REQUIRE(b && idx && batch > 0, "bad arguments to sac_gather");
     SAC_HIP(hipSetDevice(b->device));
+    if (readahead_rollback(b)) return -1;        // (this call reuses the gather slots: nothing speculative may sit in them)
     for (int i = 0; i < batch; ++i)
         SAC_REQUIRE(idx[i] >= 0 && idx[i] < b->size, "index %lld out of range [0, %lld)", (long long)idx[i],
                     (long long)b->size);

@@ -163,6 +163,20 @@ struct sac_buffer {
     sac::MtState host_seen{};
     bool defer_mirror = false;                       // sac_train_loop: the mirror follows once all launches are queued
     int64_t deferred_batches = 0;
+    // Loop calls that follow each other with nothing in between that touches the generator, the rows or the slots (a
+    // driver that trains in slices; the bracket of a benchmark): behind its last draw a call draws and gathers the NEXT
+    // call's first chunk into the slots behind its own (on this buffer's stream, under its last steps), so that the next
+    // call's first step has no draw and no gather in front of it (~15 us of a call).  Speculation: the host mirror stays at
+    // the batches handed out; anything else that comes first takes it back (loop_spec_drop: the device generator is
+    // re-uploaded from the mirror).
+    static constexpr int LOOP_SPEC = 4;              // batches of a speculative first chunk (= the loop plan's first chunk)
+    bool spec_valid = false;
+    int spec_batch = 0;                              // the batch size it was drawn for
+    int64_t spec_size = 0, spec_pos = 0;             // buffer size at the draw; first slot of the chunk in the loop's slot ring
+    hipEvent_t spec_ev = nullptr;                    // behind its gather (buffer's stream)
+    int64_t loop_pos = 0;                            // where the next loop call starts in the slot ring
+    int loop_streak = 0;                             // loop calls in a row without an outside touch
+    bool in_loop = false;                            // (a loop call is submitting: its own draws are not outside touches)
     ReplayView view() const { return ReplayView{obs, act, rew, term, nobs, O, A, Ost, Ast, capacity}; }
 };
 
@@ -183,6 +197,7 @@ int launch_gather(sac_buffer *b, const int64_t *d_idx, int batch, int64_t n_batc
 // undo the stepwise interface's read-ahead (see sac_buffer::ra_ahead); to be called in front of anything that reads or
 // changes the generator's state, the buffer's rows or its size
 int readahead_rollback(sac_buffer *b);
+int loop_spec_drop(sac_buffer *b);                   // take a speculative first chunk back (see sac_buffer::spec_valid)
 // bound generator (sac_rng_bind_host): adopt a host state somebody else changed (in front of a draw) / mirror the draws
 // of n_batches x batch indices on the host state (behind it)
 int host_rng_sync_in(sac_buffer *b);

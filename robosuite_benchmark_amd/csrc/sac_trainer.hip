@@ -2690,6 +2690,8 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
     };
     hipStream_t s = t->stream;
     t->dev.eps1 = t->dev.eps2 = nullptr;
+    b->in_loop = true;                   // (this call's own draws and set-up are not outside touches of the buffer)
+    struct InLoop { sac_buffer *b; ~InLoop() { b->in_loop = false; } } in_loop_guard{b};
     if (ensure_slots(b, t->Bt, LOOP_RING)) return -1;
     if (ensure_idx(b, LOOP_RING * t->B)) return -1;
     ht("set-up done");
@@ -2713,8 +2715,16 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
         SAC_HIP(hipEventRecord(t->ev_done[1], s));
         SAC_HIP(hipStreamWaitEvent(b->stream, t->ev_done[1], 0));
     }
-    int64_t done = 0, pos = 0;
+    // a call continues in the slot ring where the previous one ended -- if all of it (and a speculative chunk behind it) fits
+    // without wrapping; else it starts at slot 0 like every call used to (the previous calls' steps are long done either way)
+    int64_t done = 0, pos = b->loop_pos;
+    if (pos + n_steps + sac_buffer::LOOP_SPEC > LOOP_RING) pos = 0;
     int timed = 0;
+    // A speculative first chunk left by the previous call (sac_buffer::spec_valid): still what this call would draw?
+    const bool spec_hit = b->spec_valid && step0 == 0 && b->spec_batch == t->Bt && b->spec_size == b->size &&
+                          n_steps >= sac_buffer::LOOP_SPEC && b->spec_pos == pos;
+    if (b->spec_valid && !spec_hit && loop_spec_drop(b)) return -1;
+    b->spec_valid = false;
     // the host mirror of the generator (sac_buffer::host_seen; np.random's own words when bound) follows in ONE piece
     // behind the last launch: ~1.3 us of host time per batch that no launch of this call has to wait for
     struct MirrorLater {
@@ -2722,11 +2732,33 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
         ~MirrorLater() { b->defer_mirror = false; if (b->deferred_batches) host_rng_advance(b, batch, b->deferred_batches); b->deferred_batches = 0; }
     } mirror_later{b, t->Bt};
     b->defer_mirror = true; b->deferred_batches = 0;
+    // The next call's first chunk, speculatively (see sac_buffer::spec_valid): only for loop calls in a row, only in slots
+    // this call does not use, drawn behind this call's LAST draw on the buffer's stream -- it runs under this call's steps.
+    // The mirror is NOT advanced: these batches have not been handed out.
+    const bool spec_ok = step0 == 0 && b->loop_streak >= 1 && pos + n_steps + sac_buffer::LOOP_SPEC <= LOOP_RING && b->size > 1 &&
+                         !getenv("SAC_LOOP_SPEC_OFF");
+    bool spec_launched = false;
+    auto launch_spec = [&](int64_t sp) -> int {
+        if (!b->spec_ev) SAC_HIP(hipEventCreateWithFlags(&b->spec_ev, hipEventDisableTiming));
+        b->ra_internal = true;           // (a draw of the library's own: no roll-back, no mirror)
+        const int rc = launch_sample(b, t->Bt, sac_buffer::LOOP_SPEC, sp * t->B, nullptr, b->stream);
+        b->ra_internal = false;
+        if (rc) return -1;
+        if (launch_gather(b, b->d_idx + sp * t->B, t->B, sac_buffer::LOOP_SPEC, b->d_slots + (size_t)sp * b->slot.slot_floats, b->slot, 1, b->stream))
+            return -1;
+        SAC_HIP(hipEventRecord(b->spec_ev, b->stream));
+        b->spec_batch = t->Bt; b->spec_size = b->size; b->spec_pos = sp;
+        b->spec_valid = true;            // (from here on the device generator is ahead of the mirror: every exit path must know)
+        spec_launched = true;
+        return 0;
+    };
     for (int c = 0; done < n_steps; ++c) {
         const int64_t first = done, want = loop_chunk_len(done);
         int64_t m = (n_steps - first < want) ? n_steps - first : want;
         // (a tail shorter than half this chunk joins it: every chunk boundary is a cross-stream wait)
         if (const int64_t rest = n_steps - first - m; rest > 0 && 2 * rest < m && m + rest <= LOOP_CH) m += rest;
+        const bool use_spec = (c == 0) && spec_hit;
+        if (use_spec) m = sac_buffer::LOOP_SPEC;       // (drawn and gathered by the previous call, at `pos`)
         if (pos + m > LOOP_RING) pos = 0;
         const int e = c % sac_trainer::NLOOP_EV;
         hipStream_t q = (c == 0) ? s : b->stream;
@@ -2739,13 +2771,21 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
         }
         // sac_last_loop_ms reports the draw and the gather of ONE chunk: chunk 1 (on the buffer's stream, which has slack)
         // when the call has one, else chunk 0 -- whose events then sit in front of the first step (~3 us each of host time)
-        if (c == 0) timed = (n_steps > m) ? 1 : 0;
-        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[0], q));
-        if (launch_sample(b, t->Bt, m, pos * t->B, nullptr, q)) return -1;
-        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[1], q));
-        if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1, q))
-            return -1;
-        if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[2], q));
+        if (c == 0) timed = (n_steps > m) ? 1 : (use_spec ? -1 : 0);
+        if (use_spec) {
+            // the chunk is there (normally for a long time: it ran under the previous call's last steps); the host mirror
+            // now counts its batches as handed out
+            b->deferred_batches += m;
+            hipError_t st = hipEventQuery(b->spec_ev);
+            if (st != hipSuccess) { (void)hipGetLastError(); SAC_HIP(hipStreamWaitEvent(s, b->spec_ev, 0)); }
+        } else {
+            if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[0], q));
+            if (launch_sample(b, t->Bt, m, pos * t->B, nullptr, q)) return -1;
+            if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[1], q));
+            if (launch_gather(b, b->d_idx + pos * t->B, t->B, m, b->d_slots + (size_t)pos * b->slot.slot_floats, b->slot, 1, q))
+                return -1;
+            if (c == timed) SAC_HIP(hipEventRecord(t->ev_tm[2], q));
+        }
         // Chunk 0's two bookkeeping events go BEHIND its gather: an event record between two dependent launches of a stream
         // is a packet of its own there (the gather started 10.6 us after the draw had ended instead of ~2.5: rocprofv3
         // timeline of a 20-step call).  ev[0]: start of the device span (sac_last_loop_ms; it now excludes chunk 0's draw +
@@ -2755,8 +2795,15 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
         //  hipStreamQuery then reports that stream busy and pays two runtime calls plus an in-stream wait in front of its
         //  first launch -- ~30 us of the first 20-step call behind single-step calls.)
         const bool more_chunks = m < n_steps;
-        if (c == 0) { SAC_HIP(hipEventRecord(t->ev[0], s)); if (more_chunks) SAC_HIP(hipEventRecord(b->ev[3], q)); }
+        // (chunk 0 drawn on the trainer's stream: b->ev[3] tells the buffer's stream where the generator stands -- needed by a
+        //  second chunk, and by the speculative chunk this call may leave for the next one)
+        const bool will_speculate = spec_ok && !more_chunks;      // (a single-chunk call: the speculative draw follows chunk 0's, which ran on the trainer's stream)
+        if (c == 0) { SAC_HIP(hipEventRecord(t->ev[0], s)); if (!use_spec && (more_chunks || will_speculate)) SAC_HIP(hipEventRecord(b->ev[3], q)); }
         if (c == 0) ht("chunk 0 draw + gather submitted");
+        // (the call's last chunk on the buffer's stream: the speculative chunk goes right behind its gather and IN FRONT of
+        //  the event the host polls below -- the buffer's stream then ends on a command the host has seen complete, and a
+        //  device-wide synchronisation behind the call does not block on it: +16 us measured with the chunk at the very end)
+        if (c > 0 && spec_ok && first + m == n_steps && launch_spec(pos + m)) return -1;
         if (c > 0) {
             // The chunk's slots must be gathered before its first step.  An in-stream wait for the buffer's stream costs the
             // trainer's stream ~5-10 us of idle time between two steps even when the gather finished long ago (a 20-step call
@@ -2775,7 +2822,7 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
         }
         // the generator's state is one in-order sequence: everything later on the buffer's stream follows chunk 0's draw
         // (told to that stream only now, behind chunk 0's step launches: nothing of it is in front of the first step)
-        if (c == 0 && more_chunks) SAC_HIP(hipStreamWaitEvent(b->stream, b->ev[3], 0));
+        if (c == 0 && !use_spec && (more_chunks || will_speculate)) SAC_HIP(hipStreamWaitEvent(b->stream, b->ev[3], 0));
         t->publish_diag = true;
         // "the trainer is done with this chunk's slots": only a call that wraps the slot ring ever asks (the next call
         // starts behind a drained stream) -- a short call keeps these records out of its stream (~2-5 us each)
@@ -2793,8 +2840,15 @@ static int train_loop_run(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, in
     host_rng_advance(b, t->Bt, b->deferred_batches);
     b->deferred_batches = 0;
     ht("generator mirrored on the host");
+    b->loop_pos = (pos + sac_buffer::LOOP_SPEC <= LOOP_RING) ? pos : 0;
+    if (spec_ok && !spec_launched && launch_spec(pos)) return -1;       // (single-chunk calls)
+    b->loop_streak += 1;
+    ht("next call's first chunk submitted");
     if (wait_trainer_stream(t, t->ev[1])) return -1;      // (the diagnostics are in mapped pinned memory: nothing to copy)
     ht("stream idle");
+    // (the speculative chunk finished long ago, under this call's steps: ONE look at its stream lets the runtime know, so that
+    //  a device-wide synchronisation behind this call does not go into a blocking wait for the buffer's stream: +16 us)
+    if (b->spec_valid && hipEventQuery(b->spec_ev) != hipSuccess) (void)hipGetLastError();
     if (check_fused_abort(t, lost_out) < 0) return -1;
     t->timing_pending = true;                 // (the event intervals are read when sac_last_loop_ms asks: ~1 us each)
     t->mirror_valid = false;
@@ -2813,7 +2867,10 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         if (recover_device_steps(t) < 0) return -1;
     }
     if (host_rng_sync_in(b)) return -1;            // (a bound generator: somebody else may have moved np.random)
-    if (readahead_rollback(b)) return -1;          // (batches the stepwise interface drew ahead: the generator goes back first)
+    // (batches the stepwise interface drew ahead: the generator goes back first -- a speculative first chunk of THIS call,
+    //  left by the previous loop call, is not an outside touch and stays: train_loop_run decides about it)
+    if (b->ra_ahead > 0) { if (readahead_rollback(b)) return -1; }
+    else b->ra_streak = 0;
     const MtState start = b->host_seen;            // the generator in front of the loop's first batch
     unsigned lost = 0;
     if (train_loop_run(t, b, n_steps, 0, &lost)) return -1;
@@ -2824,6 +2881,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
         // sees the same trajectory, index stream and final generator state as an undisturbed run.
         SAC_REQUIRE(lost <= (unsigned)n_steps, "internal: %u steps lost in a loop of %lld", lost, (long long)n_steps);
         const int64_t applied = n_steps - (int64_t)lost;
+        b->spec_valid = false;                     // (whatever the failed pass left for a next call: the generator is reset)
         MtState st = start;
         host_rng_skip(b, st, t->Bt, applied);
         if (host_rng_adopt(b, st)) return -1;

@@ -149,3 +149,86 @@ def test_loop_behind_work_in_flight_on_the_buffers_stream():
         for _ in range(steps):
             ref.randint(0, size, B)
         assert np.array_equal(idx, ref.randint(0, size, 64))
+
+
+@pytest.mark.parametrize("bound", [False, True])
+def test_loop_calls_in_a_row_and_what_comes_between_them(bound):
+    """Loop calls that follow each other leave the NEXT call's first chunk drawn and gathered behind their own (round 3:
+    the draw + gather in front of a call's first step is ~15 us of a 20-step call).  That chunk is speculation: whatever
+    comes first instead -- an insert, a batch of the stepwise interface, a host batch, a bare index draw, a read or a
+    re-seed of the generator, a call too short to take it, another batch size -- takes it back.  A random script of such
+    calls must give bit for bit what the stepwise interface gives (which never speculates across calls), with the
+    generator (and np.random itself, when the buffer is bound to it) in the same place after every call."""
+    from robosuite_benchmark_amd import EnvReplayBuffer
+    O, A, B, cap = 10, 3, 48, 30000
+    rs_data = np.random.RandomState(3)
+    obs = rs_data.normal(size=(cap, O)).astype(np.float32); nobs = rs_data.normal(size=(cap, O)).astype(np.float32)
+    act = rs_data.uniform(-1, 1, (cap, A)).astype(np.float32); rew = rs_data.uniform(0, 1, (cap, 1)).astype(np.float32)
+    term = np.zeros((cap, 1), np.uint8)
+    _, ta = make_pair(O, A, B, seed=4, noise_seed=5)
+    _, tb = make_pair(O, A, B, seed=4, noise_seed=5)
+    ba = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)
+    bb = EnvReplayBuffer(cap, obs_dim=O, action_dim=A)
+    size = 4000
+    for b in (ba, bb):
+        b.add_block(obs[:size], act[:size], rew[:size], nobs[:size], term[:size])
+    bb.seed(21)                                              # the reference run: a private stream, stepwise interface
+    ref = np.random.RandomState(21)
+    if bound:
+        np.random.seed(21)                                   # ba samples np.random itself (construction default)
+        assert ba._bound
+    else:
+        ba.seed(21)
+    script = np.random.RandomState(11)
+
+    def steps_b(n, batch=B):
+        for _ in range(n):
+            tb.train(bb.random_batch(batch))
+            ref.randint(0, size, batch)
+
+    for it in range(120):
+        r = script.randint(0, 100)
+        if r < 60:                                           # a loop call (lengths on both sides of the chunk plan and of the ring)
+            n = int(script.choice([1, 2, 3, 4, 5, 7, 16, 20, 21, 64, 300, 509, 600]))
+            ta.train_loop(ba, n, batch_size=B)
+            steps_b(n)
+        elif r < 68:                                         # an insert between two calls
+            k = int(script.randint(1, 30))
+            for b in (ba, bb):
+                b.add_block(obs[size:size + k], act[size:size + k], rew[size:size + k], nobs[size:size + k], term[size:size + k])
+            size += k
+        elif r < 76:                                         # a batch of the stepwise interface
+            ta.train(ba.random_batch(B))
+            steps_b(1)
+        elif r < 82:                                         # a host batch, a bare index draw
+            _, ia = ba.random_batch(20, return_indices=True)
+            _, ib = bb.random_batch(20, return_indices=True)
+            assert np.array_equal(ia, ib) and np.array_equal(ia, ref.randint(0, size, 20))
+            assert np.array_equal(ba.sample_indices(9, 2), bb.sample_indices(9, 2))
+            ref.randint(0, size, 9); ref.randint(0, size, 9)
+        elif r < 88:                                         # the generator is re-seeded
+            sd = int(script.randint(0, 1 << 30))
+            ref = np.random.RandomState(sd)
+            bb.seed(sd)
+            if bound:
+                np.random.seed(sd)
+            else:
+                ba.seed(sd)
+        elif r < 94 and bound:                               # a host consumer of np.random
+            x = np.random.uniform(size=4)
+            assert np.array_equal(x, ref.uniform(size=4))
+            bb.seed_from_numpy(ref)
+        else:                                                # another batch size for one call
+            ta.train_loop(ba, 6, batch_size=32)
+            steps_b(6, 32)
+        (ka, pa), (kb, pb) = ba.rng_state(), bb.rng_state()
+        st = ref.get_state()
+        assert pa == pb == st[2] and np.array_equal(ka, kb) and np.array_equal(ka, st[1]), it
+        if bound:
+            g = np.random.get_state()
+            assert g[2] == st[2] and np.array_equal(g[1], st[1]), it
+    ta._lib.sac_sync(ta._h); tb._lib.sac_sync(tb._h)
+    sa, sb = ta.state_dict(), tb.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
