@@ -210,6 +210,25 @@ def test_a_lost_producer_falls_back_transparently_inside_the_loop_call():
     _same(fused.state_dict(), plain.state_dict())
 
 
+def test_a_lost_producer_inside_a_call_that_started_on_a_speculative_chunk():
+    """Loop calls in a row: the third call's first chunk was drawn and gathered by the second (speculation, the generator's
+    mirror still in front of it).  Launch 12 -- the second step of that third call -- loses a producer: the replay must start
+    from the state in front of the speculative chunk's batches."""
+    O, A, B = 42, 7, 256
+    fused, plain = _pair_of_hip(O, A, B, seed=4, noise_seed=9, SAC_FUSED_TEST_STALL=12)
+    bufs = [_buffer(4000, O, A, 8), _buffer(4000, O, A, 8)]
+    for b in bufs:
+        b.seed(31)
+    for n in (5, 5, 10, 7):
+        _, la = fused.train_loop(bufs[0], n, batch_size=B)
+        _, lb = plain.train_loop(bufs[1], n, batch_size=B)
+        assert np.array_equal(la, lb), n
+        (ka, pa), (kb, pb) = bufs[0].rng_state(), bufs[1].rng_state()
+        assert pa == pb and np.array_equal(ka, kb), n
+    assert not fused.is_fused()
+    _same(fused.state_dict(), plain.state_dict())
+
+
 @pytest.mark.parametrize("stall_at,steps", [(1, 5), (40, 100), (57, 60)])
 def test_a_lost_producer_falls_back_transparently_on_the_stepwise_interface(stall_at, steps):
     """The reference's own loop -- random_batch(); train() on device batches, nobody waiting for a step -- with launch
