@@ -206,6 +206,16 @@ enum {
 };
 
 int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg);
+/* hidden_sizes of ANY depth (variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'], /root/reference/util/arguments.py:98,104;
+ * FlattenMlp / TanhGaussianPolicy take a list of any length: /root/reference/util/rlkit_utils.py:64-97): 1..7 hidden layers
+ * of 1..4096 units per network family (cfg->hidden / policy_hidden / qf_hidden are ignored).  Two hidden layers of at most
+ * 256 units -- every shipped variant.json -- run on the fused kernels exactly as with sac_trainer_create; every other shape
+ * runs the GENERAL step: the same step in the same order as a sequence of 2 Lp + 2 Lq + 11 launches around one
+ * matrix-product kernel (csrc/sac_general.h), results within fp32 round-off of the oracle like the fused kernels'
+ * (tests/test_gpu_general_shapes.py); sac_trainer_step_kind reports 3.  Every sac_* entry point works on such a handle except
+ * sac_profile_loop.  SAC only (TD3 handles keep the two layers of at most 256 units). */
+int sac_trainer_create_mlp(sac_trainer_t **out, const sac_config_t *cfg, const int32_t *policy_hidden, int32_t n_policy_hidden,
+                           const int32_t *qf_hidden, int32_t n_qf_hidden);
 int sac_trainer_destroy(sac_trainer_t *t);
 
 /* flat fp32 parameter vector of one net, nn.Linear layout (W (out,in) row-major, then b):
@@ -258,7 +268,8 @@ int sac_trainer_is_fused(const sac_trainer_t *t);
 /* How a trainer's step is launched: 0 = four launches (k_fwd_a, k_fwd_b, k_bwd, k_dw_adam); 1 = the fused step above
  * (k_abc, k_dw_adam: batches up to 256 rows); 2 = three launches for batches whose 256-wide layers are not split over
  * workgroups (1024 rows and more): the two forward launches as ONE, k_chain -- a workgroup runs the policy, takes its own
- * head and goes on into the Q nets, no hand-off involved -- then k_bwd and k_dw_adam.  (TD3: always 0.) */
+ * head and goes on into the Q nets, no hand-off involved -- then k_bwd and k_dw_adam; 3 = the general step of
+ * sac_trainer_create_mlp (network shapes beyond the fused kernels').  (TD3: 0 or 1.) */
 int sac_trainer_step_kind(const sac_trainer_t *t);
 
 /* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop (total_ms == steps_ms: first

@@ -1,0 +1,408 @@
+// The SAC step for network shapes beyond the fast kernels' two hidden layers of at most 256 units
+// (variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'], /root/reference/util/arguments.py:98,104 -> FlattenMlp /
+// TanhGaussianPolicy at /root/reference/util/rlkit_utils.py:64-97): any depth, any width.  Included by sac_trainer.hip
+// inside namespace sac (device part); the host part is sac_general_host.h.
+//
+// Same step, same order, as a sequence of launches instead of fused row-block kernels:
+//   k_g_prep     rows of the slot -> the two input matrices (policy: [obs ; next_obs], Q nets: [obs|act ; obs|. ; next_obs|.])
+//   k_g_gemm     ONE kernel for every matrix product of the step -- layer forward (X W^T + b, relu), backward through a
+//                layer (dY W, masked by the relu of the layer below), weight gradient (dY^T X, the bias gradient as an
+//                extra column of ones) -- as a table of jobs per launch: a launch carries every network's job of one
+//                stage (Q1, Q2 and both targets' layer l are ONE launch).  64 x 64 output tiles, fp32 MFMA 16x16x4,
+//                operands staged through LDS with generic strides.
+//   k_g_head     tanh-Gaussian head on both policy passes (rsample, log-prob)
+//   k_g_alpha    mean(log_pi) -> Adam step on log_alpha
+//   k_g_loss     min over the twin nets, Bellman target, the loss gradients of the four Q passes that have one
+//   k_g_polgrad  head gradient of the reparameterised actor loss
+//   k_g_adam     Adam on every trained parameter + Polyak average of the targets (flat vectors)
+//   k_g_diag     the diagnostics vector
+// Weights live in nn.Linear layout (W [out][in] row-major, then b), activations row-major [row][feature]; rows = the
+// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 11 launches per step (19 for two hidden layers): this path is for
+// shapes the reference can be configured with but no shipped variant uses -- the shipped ones take the fused kernels.
+#pragma once
+
+namespace gen {
+
+constexpr int GMAXL = 8;            // layers of one network: up to 7 hidden layers + the output layer
+constexpr int GMAXJ = 24;           // jobs of one launch (the weight-gradient launch: 3 networks x GMAXL)
+constexpr int GT = 64;              // output tile (rows and columns)
+constexpr int GLD = GT + 4;         // LDS row stride of a staged operand chunk
+
+struct GemmJob {
+    const float *A;                 // A(m, r) = A[m sa_m + r sa_r]
+    const float *Bm;                // B(n, r) = Bm[n sb_n + r sb_r]
+    float *C;                       // C(m, n) = sum_r A(m, r) B(n, r)  [+ bias(n)]  [relu]  [0 where mask(m, n) <= 0]
+    const float *bias, *mask;
+    float *c_ones;                  // ones_col: B gets a column n == N of ones, whose sums go here (c_ones[m]): a bias gradient
+    long long sa_m, sa_r, sb_n, sb_r, ldc, ldmask;
+    int M, N, R;
+    int relu, ones_col, tiles_n, tile0, pad_;
+};
+struct GemmStage {                  // kernel argument: the jobs of one launch (device array) + their first tiles
+    const GemmJob *jobs;
+    int njobs, ntiles;
+    int tile0[GMAXJ];
+};
+
+// everything the elementwise kernels need
+struct GDev {
+    int n, O, A, NI;                // rows (true batch); NI: noise index stride per row (16 up to 16 actions, else 64)
+    int ldq;                        // O + A
+    float discount, reward_scale, tau, target_entropy, alpha_lr;
+    int period, auto_alpha;
+    unsigned long long noise_seed;
+    Ctl *ctl;
+    float *XP, *XQ;                 // [2n][O], [3n][O + A]
+    const float *HD;                // head pre-activations [2n][2A]: mean | log-std
+    float *mu, *ls, *ok, *epsv, *anew, *a2, *logpi, *logpi2;
+    const float *QO[4];             // q1 [2n] (s,a | s,a_new), q2 [2n], target q1 [n], target q2 [n]
+    float *DQ[2];                   // dL/dq of the critic rows | of the actor rows [2n]
+    float *y, *qn;                  // Bellman target [n]; min Q(s, a_new) [n]
+    const float *DA[2];             // actor-loss gradient w.r.t. a_new through Q1 / Q2 [n][A]
+    float *DHD;                     // head gradient [n][2A]
+    float *diag_first, *diag_last, *diag_trace, *diag_dev;
+    const float *eps1, *eps2;
+};
+
+struct AdamArgs {
+    float *P[3], *M[3], *V[3], *TP[3];
+    const float *G[3];
+    long long n[3];
+    float lr[3];
+};
+
+// ------------------------------------------------------------------------------------------
+// the matrix-product kernel
+// ------------------------------------------------------------------------------------------
+// A workgroup owns a 64 x 64 tile of C; wave w its rows 16 w .. 16 w + 15 (four 16 x 16 MFMA accumulators).  The reduction
+// runs in chunks of 64: each thread fetches 16 values per operand (a wave reads 256 contiguous bytes along whichever
+// direction the operand is contiguous in), the chunk goes to LDS as [slow][fast] -- [row][r] for an operand that is
+// contiguous along the reduction, [r][row] otherwise: conflict-free writes either way -- and the next chunk's loads are in
+// flight while this one's 64 MFMAs per wave run.  The MFMA with index i of k-group (q, g) contracts r = 16 q + 4 g + i for
+// both operands, so an operand stored [row][r] is read with one 16-byte LDS load per four MFMAs.
+constexpr int GK = 64;
+__global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
+    __shared__ __attribute__((aligned(16))) float As[GT * GLD], Bs[GT * GLD];
+    int li = 0;
+#pragma unroll
+    for (int q = 1; q < GMAXJ; ++q) li = ((int)blockIdx.x >= T.tile0[q]) ? q : li;
+    union { GemmJob J; unsigned long long w[sizeof(GemmJob) / 8]; } ud;
+    {
+        const __attribute__((address_space(4))) unsigned long long *src =
+            (const __attribute__((address_space(4))) unsigned long long *)(uintptr_t)(T.jobs + li);
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(GemmJob) / 8); ++q) ud.w[q] = src[q];
+    }
+    const GemmJob &J = ud.J;
+    const int tile = (int)blockIdx.x - J.tile0;
+    const int m0 = GT * (tile / J.tiles_n), n0 = GT * (tile % J.tiles_n);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int Neff = J.N + (J.ones_col ? 1 : 0);
+    const bool a_rc = (J.sa_r == 1), b_rc = (J.sb_r == 1);       // operand contiguous along the reduction?
+    // This thread's 16 elements of a chunk: fast coordinate `lane`, slow coordinates wave + 4 j (the row for an operand that is
+    // contiguous along the reduction, else the reduction index).  Loads are UNCONDITIONAL from clamped indices -- a row or
+    // column beyond the matrix repeats the last one (its products land in outputs that are never stored), the reduction's
+    // padding is zeroed in the last chunk only -- and go through explicitly GLOBAL pointers.  Both matter: a conditional
+    // load is a branch whose merge point waits for the data, and a generic pointer (these come out of a table read with
+    // scalar loads) makes a flat load, which counts on lgkmcnt too, so that every wait for an LDS read of the chunk
+    // being multiplied also waited for the next chunk's loads.  Offsets are 32-bit (checked at creation).
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int sa_m = (int)J.sa_m, sa_r = (int)J.sa_r, sb_n = (int)J.sb_n, sb_r = (int)J.sb_r;
+    int xoa[16], xob[16];                      // rc: the 16 rows' offsets; else [0]: this thread's row offset
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ra = min(m0 + (a_rc ? wv + 4 * j : lane), J.M - 1), rb = min(n0 + (b_rc ? wv + 4 * j : lane), J.N - 1);
+        xoa[j] = ra * sa_m; xob[j] = rb * sb_n;
+    }
+    const bool has_ones = J.ones_col && n0 <= J.N && J.N < n0 + GT;
+    float xa[16], xb[16];
+    auto fetch = [&](int s) {
+        const int r0 = GK * s;
+        if (a_rc) {
+            const int ro = min(r0 + lane, J.R - 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xa[j] = ld1g(J.A + (xoa[j] + ro));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xa[j] = ld1g(J.A + (xoa[0] + min(r0 + wv + 4 * j, J.R - 1) * sa_r));
+        }
+        if (b_rc) {
+            const int ro = min(r0 + lane, J.R - 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xb[j] = ld1g(J.Bm + (xob[j] + ro));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xb[j] = ld1g(J.Bm + (xob[0] + min(r0 + wv + 4 * j, J.R - 1) * sb_r));
+        }
+    };
+    // behind the loads' arrival (in front of the LDS writes): the column of ones, the reduction's zero padding
+    auto fixup = [&](int s) {
+        const int r0 = GK * s;
+        if (has_ones) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (n0 + (b_rc ? wv + 4 * j : lane) == J.N) xb[j] = 1.0f;
+        }
+        if (r0 + GK > J.R) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (r0 + (a_rc ? lane : wv + 4 * j) >= J.R) xa[j] = 0.f;
+                if (r0 + (b_rc ? lane : wv + 4 * j) >= J.R) xb[j] = 0.f;
+            }
+        }
+    };
+    f32x4 acc[4] = {};
+    const int nS = (J.R + GK - 1) / GK;
+    fetch(0);
+    for (int s = 0; s < nS; ++s) {
+        if (s) __syncthreads();
+        fixup(s);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { As[(wave + 4 * j) * GLD + lane] = xa[j]; Bs[(wave + 4 * j) * GLD + lane] = xb[j]; }
+        __syncthreads();
+        if (s + 1 < nS) fetch(s + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a, b[4];
+            if (a_rc) a = ld4(As + (16 * wave + c) * GLD + 16 * q + 4 * g);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = As[(16 * q + 4 * g + i) * GLD + 16 * wave + c];
+            }
+            if (b_rc) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = ld4(Bs + (16 * t + c) * GLD + 16 * q + 4 * g);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) b[t][i] = Bs[(16 * q + 4 * g + i) * GLD + 16 * t + c];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int n = n0 + 16 * t + c;
+        if (n >= Neff) continue;
+        const bool ones = J.ones_col && n == J.N;
+        const float bv = (J.bias && !ones) ? J.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + 16 * wave + 4 * g + i;
+            if (m >= J.M) continue;
+            float v = acc[t][i];
+            if (ones) { J.c_ones[m] = v; continue; }
+            v += bv;
+            if (J.relu) v = fmaxf(v, 0.f);
+            if (J.mask) v = (J.mask[(long long)m * J.ldmask + n] > 0.f) ? v : 0.f;
+            J.C[(long long)m * J.ldc + n] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise kernels
+// ------------------------------------------------------------------------------------------
+// np_to_pytorch_batch + the torch.cat of FlattenMlp: the slot's rows into the input matrices
+__global__ __launch_bounds__(256) void k_g_prep(GDev d, const float *__restrict__ S, SlotLayout SL) {
+    const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    const long long tot = (long long)n * (2 * O + A);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int b = (int)(e / (2 * O + A)), k = (int)(e % (2 * O + A));
+        if (k < O) {
+            const float v = S[SL.off_obs + (long long)b * O + k];
+            d.XP[(long long)b * O + k] = v;
+            d.XQ[(long long)b * ldq + k] = v;
+            d.XQ[(long long)(n + b) * ldq + k] = v;
+        } else if (k < 2 * O) {
+            const float v = S[SL.off_nobs + (long long)b * O + (k - O)];
+            d.XP[(long long)(n + b) * O + (k - O)] = v;
+            d.XQ[(long long)(2 * n + b) * ldq + (k - O)] = v;
+        } else {
+            d.XQ[(long long)b * ldq + O + (k - 2 * O)] = S[SL.off_act + (long long)b * A + (k - 2 * O)];
+        }
+    }
+}
+
+// TanhGaussianPolicy.forward(reparameterize=True, return_log_prob=True) behind the head layer, both passes: one thread
+// per row (side 0: policy(s), side 1: policy(s')); the new actions go straight into the Q nets' input rows
+__global__ __launch_bounds__(256) void k_g_head(GDev d, StepArg sa) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * d.n) return;
+    const int n = d.n, A = d.A, side = r >= n ? 1 : 0, b = r - side * n;
+    const float *epp = side ? d.eps2 : d.eps1;
+    const float *hd = d.HD + (long long)r * 2 * A;
+    float lsum = 0.f;
+    for (int a = 0; a < A; ++a) {
+        const float mean = hd[a], raw = hd[A + a];
+        const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+        const float stdv = expf(lstd);
+        const float eps = epp ? epp[(long long)b * A + a]
+                              : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(b * d.NI + a), side ? 1u : 0u);
+        const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));            // TanhNormal.rsample
+        const float act = tanhf(zz);
+        const float dd = __fsub_rn(zz, mean);                               // Normal.log_prob(z) - log(1 - a^2 + eps)
+        const float var = __fmul_rn(stdv, stdv);
+        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+        lsum += nlp - logf(1.0f - act * act + TANH_EPS);
+        const long long gi = (long long)b * A + a;
+        if (!side) {
+            d.mu[gi] = mean; d.ls[gi] = lstd; d.ok[gi] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.0f : 0.0f;
+            d.epsv[gi] = eps; d.anew[gi] = act;
+            d.XQ[(long long)(n + b) * d.ldq + d.O + a] = act;
+        } else {
+            d.a2[gi] = act;
+            d.XQ[(long long)(2 * n + b) * d.ldq + d.O + a] = act;
+        }
+    }
+    (side ? d.logpi2 : d.logpi)[b] = lsum;
+}
+
+// SURVEY Appendix A lines 4-6: alpha_loss = -mean(log_alpha (log_pi + H)), one Adam step on log_alpha, alpha = exp(.)
+// (post-step).  One workgroup; the sum runs in a fixed order.
+__global__ __launch_bounds__(256) void k_g_alpha(GDev d, StepArg sa) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < d.n; i += 256) s += d.logpi[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    Ctl *c = d.ctl;
+    if (!d.auto_alpha) { c->alpha = 1.0f; c->alpha_loss = 0.0f; return; }
+    const float la = c->log_alpha, m0 = c->a_m, v0 = c->a_v;
+    const float mean_lp = red[0] / (float)d.n + d.target_entropy;
+    const float gr = -mean_lp;
+    const float m = m0 + ADAM_1MB1 * (gr - m0);
+    const float v = v0 * ADAM_B2 + ADAM_1MB2 * gr * gr;
+    const float step_size = (float)((double)d.alpha_lr / sa.bc1);
+    const float denom = sqrtf(v) / (float)sa.bc2s + 1e-8f;
+    const float nla = la + (-step_size * m) / denom;
+    c->alpha_loss = -((la * mean_lp) + 0.0f);
+    c->log_alpha = nla; c->a_m = m; c->a_v = v; c->alpha = expf(nla);
+}
+
+// min over the twin nets (actor loss, target), the Bellman target, and dL/dq of the passes that carry a gradient:
+// critic rows 2 (q - y) / n, actor rows -1/n to the smaller of Q1, Q2(s, a_new) (torch.min: a tie splits it)
+__global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict__ S, SlotLayout SL) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= d.n) return;
+    const int n = d.n;
+    const float invB = 1.0f / (float)n;
+    const float alpha = d.ctl->alpha;
+    const float q1 = d.QO[0][b], q2 = d.QO[1][b], qa = d.QO[0][n + b], qb = d.QO[1][n + b];
+    const float tq = fminf(d.QO[2][b], d.QO[3][b]) - alpha * d.logpi2[b];
+    const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, tq);
+    d.y[b] = y;
+    d.qn[b] = fminf(qa, qb);
+    d.DQ[0][b] = 2.0f * (q1 - y) * invB;
+    d.DQ[1][b] = 2.0f * (q2 - y) * invB;
+    const float sel1 = (qa < qb) ? 1.0f : ((qa == qb) ? 0.5f : 0.0f);
+    d.DQ[0][n + b] = -invB * sel1;
+    d.DQ[1][n + b] = -invB * (1.0f - sel1);
+}
+
+// d/d(mean, log_std) of mean(alpha log_pi - min Q) through a = tanh(mean + std eps)
+__global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)d.n * d.A) return;
+    const int b = (int)(e / d.A), a = (int)(e % d.A);
+    const float alpha_invB = __fmul_rn(d.ctl->alpha, 1.0f / (float)d.n);
+    const float da = d.DA[0][e] + d.DA[1][e];
+    const float act = d.anew[e];
+    const float om = 1.0f - act * act;
+    const float dz = actor_dz(da, om, alpha_invB, act);
+    const float dls = actor_dls(dz, expf(d.ls[e]), d.epsv[e], alpha_invB, d.ok[e]);
+    d.DHD[(long long)b * 2 * d.A + a] = dz;
+    d.DHD[(long long)b * 2 * d.A + d.A + a] = dls;
+}
+
+// torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets
+__global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) {
+    const bool polyak = (sa.step_now % d.period) == 0;
+    const float bc2s = (float)sa.bc2s;
+    const long long tot = P.n[0] + P.n[1] + P.n[2];
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+        const int k = e < P.n[0] ? 0 : (e < P.n[0] + P.n[1] ? 1 : 2);
+        const long long i = e - (k > 0 ? P.n[0] : 0) - (k > 1 ? P.n[1] : 0);
+        float p = P.P[k][i], m = P.M[k][i], v = P.V[k][i];
+        adam_update(p, m, v, P.G[k][i], (float)((double)P.lr[k] / sa.bc1), bc2s);
+        P.P[k][i] = p; P.M[k][i] = m; P.V[k][i] = v;
+        if (polyak && P.TP[k]) P.TP[k][i] = P.TP[k][i] * (1.0f - d.tau) + p * d.tau;
+    }
+}
+
+// the diagnostics vector (SURVEY Appendix A line 17); one workgroup, sums in double
+__global__ __launch_bounds__(256) void k_g_diag(GDev d, StepArg sa) {
+    constexpr int NQ = 28;
+    // 0-3 q1 (sum, sum sq, max, min)  4-7 q2  8-11 y  12-15 log_pi  16 (q1-y)^2  17 (q2-y)^2  18 log_pi - q_new
+    // 19 alpha log_pi - q_new  20-23 mu  24-27 log_std
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = ((q & 3) == 2 && (q < 16 || q >= 20)) ? -INFINITY : (((q & 3) == 3 && (q < 16 || q >= 20)) ? INFINITY : 0.0);
+    const int n = d.n, A = d.A;
+    const float alpha = d.ctl->alpha;
+    auto stat = [&](int q0, float v) {
+        acc[q0] += (double)v; acc[q0 + 1] += (double)v * (double)v;
+        acc[q0 + 2] = fmax(acc[q0 + 2], (double)v); acc[q0 + 3] = fmin(acc[q0 + 3], (double)v);
+    };
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float q1 = d.QO[0][i], q2 = d.QO[1][i], y = d.y[i], lp = d.logpi[i], qn = d.qn[i];
+        stat(0, q1); stat(4, q2); stat(8, y); stat(12, lp);
+        const float e1 = q1 - y, e2 = q2 - y;
+        acc[16] += (double)(e1 * e1); acc[17] += (double)(e2 * e2);
+        acc[18] += (double)(lp - qn); acc[19] += (double)(alpha * lp - qn);
+        for (int a = 0; a < A; ++a) { stat(20, d.mu[(long long)i * A + a]); stat(24, d.ls[(long long)i * A + a]); }
+    }
+    __shared__ double part[4][NQ];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const bool stq = q < 16 || q >= 20;
+        const int kind = stq ? (q & 3) : 0;          // 0/1 sum, 2 max, 3 min
+        double v = acc[q];
+        for (int o = 32; o > 0; o >>= 1) {
+            const double w = __shfl_xor(v, o);
+            v = kind == 2 ? fmax(v, w) : (kind == 3 ? fmin(v, w) : v + w);
+        }
+        if (lane == 0) part[wave][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double tot[NQ];
+    for (int q = 0; q < NQ; ++q) {
+        const bool stq = q < 16 || q >= 20;
+        const int kind = stq ? (q & 3) : 0;
+        double v = part[0][q];
+        for (int w = 1; w < 4; ++w) v = kind == 2 ? fmax(v, part[w][q]) : (kind == 3 ? fmin(v, part[w][q]) : v + part[w][q]);
+        tot[q] = v;
+    }
+    float out[SAC_DIAG_N];
+    for (int i = 0; i < SAC_DIAG_N; ++i) out[i] = 0.f;
+    out[SAC_D_QF1_LOSS] = (float)(tot[16] / n); out[SAC_D_QF2_LOSS] = (float)(tot[17] / n);
+    out[SAC_D_POLICY_LOSS] = (float)(tot[18] / n); out[SAC_D_ACTOR_LOSS] = (float)(tot[19] / n);
+    const int base[6] = {0, 4, 8, 12, 20, 24};
+    for (int s = 0; s < 6; ++s) {
+        const double cnt = s < 4 ? (double)n : (double)n * A;
+        const double mean = tot[base[s]] / cnt;
+        double var = tot[base[s] + 1] / cnt - mean * mean;
+        if (var < 0) var = 0;
+        out[SAC_D_Q1_MEAN + 4 * s + 0] = (float)mean; out[SAC_D_Q1_MEAN + 4 * s + 1] = (float)sqrt(var);
+        out[SAC_D_Q1_MEAN + 4 * s + 2] = (float)tot[base[s] + 2]; out[SAC_D_Q1_MEAN + 4 * s + 3] = (float)tot[base[s] + 3];
+    }
+    out[SAC_D_ALPHA] = alpha; out[SAC_D_ALPHA_LOSS] = d.ctl->alpha_loss;
+    float *const dlast = (sa.pad2 & 2u) ? d.diag_last : d.diag_dev;
+    for (int i = 0; i < 30; ++i) {
+        dlast[i] = out[i];
+        if (sa.loop_pos == 0) d.diag_first[i] = out[i];
+        if (sa.loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)sa.loop_pos * SAC_DIAG_N + i] = out[i];
+    }
+}
+
+}  // namespace gen

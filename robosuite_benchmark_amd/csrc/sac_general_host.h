@@ -1,0 +1,338 @@
+// Host side of the general-shape SAC step (sac_general.h): network tables, the job lists of the matrix-product
+// launches, parameter transfer, the step's launch sequence.  Included by sac_trainer.hip behind struct sac_trainer.
+#pragma once
+
+struct GenLayer { int N = 0, K = 0; long long offW = 0, offB = 0; };
+struct GenNet {
+    int nl = 0;
+    GenLayer L[gen::GMAXL];
+    long long n = 0;
+    float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
+    std::vector<long long> perm;            // flat (sac_get_params) index -> index in the device vector
+};
+struct GenStage { int kind = 0; size_t base = 0; gen::GemmStage gs{}; };   // kind 0: a k_g_gemm launch; else see launch
+enum { GS_GEMM = 0, GS_PREP, GS_HEAD, GS_ALPHA, GS_LOSS, GS_POLGRAD, GS_ADAM, GS_DIAG };
+
+struct sac_general {
+    int n = 0, O = 0, A = 0, Lp = 0, Lq = 0;
+    int hp[gen::GMAXL] = {}, hq[gen::GMAXL] = {};
+    GenNet net[5];
+    gen::GDev dev{};
+    gen::AdamArgs adam{};
+    char *arena = nullptr;
+    gen::GemmJob *d_jobs = nullptr;
+    std::vector<GenStage> stages;
+    long long adam_total = 0;
+};
+
+namespace {
+
+struct GenBump {
+    std::vector<std::pair<void **, size_t>> req;
+    size_t total = 0;
+    template <typename T> void want(T **p, long long count) {
+        req.emplace_back(reinterpret_cast<void **>(p), total);
+        total += ((size_t)count * sizeof(T) + 255) & ~(size_t)255;
+    }
+};
+
+void gen_shape_net(GenNet &N, const int *hidden, int nh, int in_dim, int out_dim, bool merged_heads, int A) {
+    long long off = 0;
+    int d = in_dim;
+    N.nl = nh + 1;
+    for (int l = 0; l <= nh; ++l) {
+        GenLayer &L = N.L[l];
+        L.N = (l < nh) ? hidden[l] : out_dim; L.K = d;
+        L.offW = off; off += (long long)L.N * L.K;
+        L.offB = off; off += L.N;
+        d = L.N;
+    }
+    N.n = off;
+    // flat layout: per layer W then b; the policy's two heads are two layers there (last_fc, last_fc_log_std) and ONE
+    // layer of 2A outputs here ([W_mean ; W_log_std] then [b_mean ; b_log_std])
+    N.perm.resize((size_t)off);
+    for (long long i = 0; i < off; ++i) N.perm[(size_t)i] = i;
+    if (merged_heads) {
+        const GenLayer &Hd = N.L[nh];
+        const long long h0 = Hd.offW, AK = (long long)A * Hd.K;
+        long long fi = h0;
+        for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = h0 + i;                   // last_fc.weight
+        for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = Hd.offB + a;                     // last_fc.bias
+        for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = h0 + AK + i;              // last_fc_log_std.weight
+        for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = Hd.offB + A + a;                 // last_fc_log_std.bias
+    }
+}
+
+gen::GemmJob gen_job_zero() { gen::GemmJob J; memset(&J, 0, sizeof(J)); return J; }
+
+// Y = act(X W^T + b): X [M][K], W [N][K]
+gen::GemmJob gen_fwd(const float *X, int M, const float *W, const float *b, int N, int K, float *Y, int relu) {
+    gen::GemmJob J = gen_job_zero();
+    J.A = X; J.sa_m = K; J.sa_r = 1;
+    J.Bm = W; J.sb_n = K; J.sb_r = 1;
+    J.C = Y; J.ldc = N; J.bias = b; J.relu = relu;
+    J.M = M; J.N = N; J.R = K;
+    return J;
+}
+// dX[:, c0 : c0 + ncols] = dY W[:, c0 : c0 + ncols], zero where mask <= 0: dY [M][Nl], W [Nl][K]
+gen::GemmJob gen_bwd(const float *dY, int M, int Nl, const float *W, int K, int c0, int ncols, float *dX, int lddx,
+                     const float *mask, int ldmask) {
+    gen::GemmJob J = gen_job_zero();
+    J.A = dY; J.sa_m = Nl; J.sa_r = 1;
+    J.Bm = W + c0; J.sb_n = 1; J.sb_r = K;
+    J.C = dX; J.ldc = lddx; J.mask = mask; J.ldmask = ldmask;
+    J.M = M; J.N = ncols; J.R = Nl;
+    return J;
+}
+// dW = dY^T X over `rows` rows, db = column sums of dY: dY [rows][Nl], X [rows][K]
+gen::GemmJob gen_dw(const float *dY, const float *X, int rows, int Nl, int K, float *GW, float *Gb) {
+    gen::GemmJob J = gen_job_zero();
+    J.A = dY; J.sa_m = 1; J.sa_r = Nl;
+    J.Bm = X; J.sb_n = 1; J.sb_r = K;
+    J.C = GW; J.ldc = K; J.c_ones = Gb; J.ones_col = 1;
+    J.M = Nl; J.N = K; J.R = rows;
+    return J;
+}
+
+int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
+    sac_general *g = new sac_general();
+    t->gen = g;
+    const int n = t->Bt, O = t->O, A = t->A;
+    g->n = n; g->O = O; g->A = A; g->Lp = np_; g->Lq = nq_;
+    for (int i = 0; i < np_; ++i) g->hp[i] = hp[i];
+    for (int i = 0; i < nq_; ++i) g->hq[i] = hq[i];
+    gen_shape_net(g->net[0], hp, np_, O, 2 * A, true, A);
+    for (int i = 1; i < 5; ++i) gen_shape_net(g->net[i], hq, nq_, O + A, 1, false, A);
+    const int Lp = np_, Lq = nq_, ldq = O + A;
+    {   // the matrix-product kernel indexes its operands with 32-bit offsets
+        long long widest = ldq;
+        for (int i = 0; i < np_; ++i) widest = hp[i] > widest ? hp[i] : widest;
+        for (int i = 0; i < nq_; ++i) widest = hq[i] > widest ? hq[i] : widest;
+        SAC_REQUIRE(3LL * n * widest < (1LL << 31) && widest * widest < (1LL << 31),
+                    "batch %d x layer width %lld is beyond the general step's 32-bit operand offsets", n, widest);
+    }
+
+    GenBump bump;
+    for (int i = 0; i < 5; ++i) {
+        bump.want(&g->net[i].P, g->net[i].n);
+        if (i < 3) { bump.want(&g->net[i].M, g->net[i].n); bump.want(&g->net[i].V, g->net[i].n); bump.want(&g->net[i].G, g->net[i].n); }
+    }
+    gen::GDev &d = g->dev;
+    float *PH[gen::GMAXL] = {}, *dPZ[gen::GMAXL] = {}, *HD = nullptr;
+    float *QH[2][gen::GMAXL] = {}, *TH[2][gen::GMAXL] = {}, *dQZ[2][gen::GMAXL] = {}, *QO[4] = {}, *DA[2] = {};
+    bump.want(&d.XP, 2LL * n * O); bump.want(&d.XQ, 3LL * n * ldq);
+    for (int l = 0; l < Lp; ++l) { bump.want(&PH[l], 2LL * n * hp[l]); bump.want(&dPZ[l], (long long)n * hp[l]); }
+    bump.want(&HD, 2LL * n * 2 * A);
+    float **rowsA[] = {&d.mu, &d.ls, &d.ok, &d.epsv, &d.anew, &d.a2};
+    for (float **p : rowsA) bump.want(p, (long long)n * A);
+    bump.want(&d.logpi, n); bump.want(&d.logpi2, n); bump.want(&d.y, n); bump.want(&d.qn, n);
+    for (int k = 0; k < 2; ++k) {
+        for (int l = 0; l < Lq; ++l) {
+            bump.want(&QH[k][l], 2LL * n * hq[l]); bump.want(&TH[k][l], (long long)n * hq[l]); bump.want(&dQZ[k][l], 2LL * n * hq[l]);
+        }
+        bump.want(&QO[k], 2LL * n); bump.want(&QO[2 + k], n); bump.want(&d.DQ[k], 2LL * n); bump.want(&DA[k], (long long)n * A);
+    }
+    bump.want(&d.DHD, (long long)n * 2 * A);
+    // shared with the entry points of sac_trainer.hip: host-batch slot, caller-supplied noise, diagnostics, entropy state
+    t->ext_layout = make_slot_layout(t->Bt, O, A);
+    bump.want(&t->ext_slot, t->ext_layout.slot_floats);
+    bump.want(&t->d_eps, 2LL * t->B * A);
+    bump.want(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP));
+    bump.want(&t->d_ctl, 1);
+    bump.want(&g->d_jobs, 16 * gen::GMAXJ);
+    {
+        const size_t bytes = (bump.total + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->arena), bytes));
+        SAC_HIP(hipMemsetAsync(g->arena, 0, bytes, t->stream));
+        for (auto &r : bump.req) *r.first = g->arena + r.second;
+    }
+    const sac_config_t &cfg = t->cfg;
+    d.n = n; d.O = O; d.A = A; d.NI = 16; d.ldq = ldq;
+    d.discount = cfg.discount; d.reward_scale = cfg.reward_scale; d.tau = cfg.soft_target_tau;
+    d.target_entropy = std::isnan(cfg.target_entropy) ? -(float)A : cfg.target_entropy;
+    d.alpha_lr = cfg.policy_lr; d.period = cfg.target_update_period; d.auto_alpha = cfg.use_automatic_entropy_tuning;
+    d.noise_seed = cfg.noise_seed; d.ctl = t->d_ctl; d.HD = HD;
+    for (int k = 0; k < 4; ++k) d.QO[k] = QO[k];
+    for (int k = 0; k < 2; ++k) d.DA[k] = DA[k];
+    d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
+    d.diag_dev = t->d_diag;
+    d.eps1 = d.eps2 = nullptr;
+    gen::AdamArgs &ad = g->adam;
+    const float lrs[3] = {cfg.policy_lr, cfg.qf_lr, cfg.qf_lr};
+    for (int k = 0; k < 3; ++k) {
+        ad.P[k] = g->net[k].P; ad.M[k] = g->net[k].M; ad.V[k] = g->net[k].V; ad.G[k] = g->net[k].G;
+        ad.TP[k] = k == 0 ? nullptr : g->net[k + 2].P;
+        ad.n[k] = g->net[k].n; ad.lr[k] = lrs[k];
+        g->adam_total += g->net[k].n;
+    }
+
+    // ---- the launch sequence ----
+    std::vector<gen::GemmJob> jobs;
+    GenStage cur;
+    auto begin = [&]() {
+        cur = GenStage{};
+        cur.kind = GS_GEMM; cur.base = jobs.size();
+        for (int q = 0; q < gen::GMAXJ; ++q) cur.gs.tile0[q] = 1 << 30;
+    };
+    auto add = [&](gen::GemmJob J) {
+        J.tiles_n = (J.N + (J.ones_col ? 1 : 0) + gen::GT - 1) / gen::GT;
+        J.tile0 = cur.gs.ntiles;
+        cur.gs.tile0[cur.gs.njobs++] = J.tile0;
+        cur.gs.ntiles += ((J.M + gen::GT - 1) / gen::GT) * J.tiles_n;
+        jobs.push_back(J);
+    };
+    auto end = [&]() { g->stages.push_back(cur); };
+    auto plain = [&](int kind) { GenStage s; s.kind = kind; g->stages.push_back(s); };
+    auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
+    auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
+
+    plain(GS_PREP);
+    for (int l = 0; l < Lp; ++l) {                       // policy trunk on [s ; s']
+        const GenLayer &L = g->net[0].L[l];
+        begin(); add(gen_fwd(l == 0 ? d.XP : PH[l - 1], 2 * n, Wp(0, l), Bp(0, l), L.N, L.K, PH[l], 1)); end();
+    }
+    {
+        const GenLayer &L = g->net[0].L[Lp];
+        begin(); add(gen_fwd(PH[Lp - 1], 2 * n, Wp(0, Lp), Bp(0, Lp), L.N, L.K, HD, 0)); end();
+    }
+    plain(GS_HEAD);
+    plain(GS_ALPHA);
+    for (int l = 0; l <= Lq; ++l) {                      // Q1, Q2 on [(s,a) ; (s,a_new)], targets on (s',a')
+        begin();
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[1 + k].L[l];
+            float *out = l < Lq ? QH[k][l] : QO[k];
+            add(gen_fwd(l == 0 ? d.XQ : QH[k][l - 1], 2 * n, Wp(1 + k, l), Bp(1 + k, l), L.N, L.K, out, l < Lq));
+        }
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[3 + k].L[l];
+            float *out = l < Lq ? TH[k][l] : QO[2 + k];
+            add(gen_fwd(l == 0 ? d.XQ + 2LL * n * ldq : TH[k][l - 1], n, Wp(3 + k, l), Bp(3 + k, l), L.N, L.K, out, l < Lq));
+        }
+        end();
+    }
+    plain(GS_LOSS);
+    for (int j = Lq; j >= 1; --j) {                      // backward through layer j of Q1, Q2 (critic and actor rows)
+        begin();
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[1 + k].L[j];
+            add(gen_bwd(j == Lq ? d.DQ[k] : dQZ[k][j], 2 * n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
+        }
+        end();
+    }
+    begin();                                             // the actor rows' gradient w.r.t. the action columns of the input
+    for (int k = 0; k < 2; ++k) {
+        const GenLayer &L = g->net[1 + k].L[0];
+        add(gen_bwd(dQZ[k][0] + (long long)n * L.N, n, L.N, Wp(1 + k, 0), L.K, O, A, DA[k], A, nullptr, 0));
+    }
+    end();
+    plain(GS_POLGRAD);
+    for (int j = Lp; j >= 1; --j) {                      // backward through the policy (rows of s only)
+        const GenLayer &L = g->net[0].L[j];
+        begin(); add(gen_bwd(j == Lp ? d.DHD : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PH[j - 1], L.K)); end();
+    }
+    begin();                                             // every weight gradient of the step
+    for (int l = Lp; l >= 0; --l) {
+        const GenLayer &L = g->net[0].L[l];
+        add(gen_dw(l == Lp ? d.DHD : dPZ[l], l == 0 ? d.XP : PH[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB));
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int l = Lq; l >= 0; --l) {
+            const GenLayer &L = g->net[1 + k].L[l];
+            add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, L.N, L.K,
+                       g->net[1 + k].G + L.offW, g->net[1 + k].G + L.offB));
+        }
+    end();
+    plain(GS_ADAM);
+    plain(GS_DIAG);
+    SAC_REQUIRE(jobs.size() <= (size_t)16 * gen::GMAXJ, "internal: %zu matrix-product jobs", jobs.size());
+    SAC_HIP(hipMemcpyAsync(g->d_jobs, jobs.data(), sizeof(gen::GemmJob) * jobs.size(), hipMemcpyHostToDevice, t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    for (auto &s : g->stages) if (s.kind == GS_GEMM) s.gs.jobs = g->d_jobs + s.base;
+    // debug views (sac_debug_fetch)
+    return 0;
+}
+
+void gen_destroy(sac_general *g) {
+    if (!g) return;
+    if (g->arena) (void)hipFree(g->arena);
+    delete g;
+}
+
+int gen_upload(sac_trainer *t, int net, const float *flat, float *dst) {
+    const GenNet &N = t->gen->net[net];
+    std::vector<float> h((size_t)N.n);
+    for (long long i = 0; i < N.n; ++i) h[(size_t)N.perm[(size_t)i]] = flat[i];
+    SAC_HIP(hipMemcpyAsync(dst, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int gen_download(sac_trainer *t, int net, const float *src, float *flat) {
+    const GenNet &N = t->gen->net[net];
+    std::vector<float> h((size_t)N.n);
+    SAC_HIP(hipMemcpyAsync(h.data(), src, sizeof(float) * h.size(), hipMemcpyDeviceToHost, t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    for (long long i = 0; i < N.n; ++i) flat[i] = h[(size_t)N.perm[(size_t)i]];
+    return 0;
+}
+
+// one step on minibatch slot S: the launch sequence built by gen_build
+int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j) {
+    sac_general *g = t->gen;
+    hipStream_t s = t->stream;
+    const double tt = (double)(t->adam_t + 1);
+    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
+    sa.pad2 = t->publish_diag ? 2u : 0u;
+    gen::GDev &d = g->dev;
+    d.eps1 = t->dev.eps1; d.eps2 = t->dev.eps2;
+    const int n = g->n, A = g->A;
+    auto blocks = [](long long work, int cap) { const long long b = (work + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); };
+    for (const GenStage &st : g->stages) {
+        switch (st.kind) {
+        case GS_GEMM: hipLaunchKernelGGL(gen::k_g_gemm, dim3(st.gs.ntiles), dim3(256), 0, s, st.gs); break;
+        case GS_PREP: hipLaunchKernelGGL(gen::k_g_prep, dim3(blocks((long long)n * (2 * g->O + A), 2048)), dim3(256), 0, s, d, S, SL); break;
+        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, dim3(blocks(2LL * n, 1 << 20)), dim3(256), 0, s, d, sa); break;
+        case GS_ALPHA: hipLaunchKernelGGL(gen::k_g_alpha, dim3(1), dim3(256), 0, s, d, sa); break;
+        case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
+        case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
+        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(blocks(g->adam_total, 2048)), dim3(256), 0, s, d, g->adam, sa); break;
+        case GS_DIAG: hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa); break;
+        }
+    }
+    SAC_HIP(hipGetLastError());
+    t->n_train_steps_total += 1;
+    t->adam_t += 1;
+    return 0;
+}
+
+// sac_debug_fetch on a general trainer: the same names, rows of the true batch
+int64_t gen_debug_fetch(sac_trainer *t, const std::string &nm, float *out, int64_t cap) {
+    sac_general *g = t->gen;
+    const gen::GDev &d = g->dev;
+    const int64_t n = g->n, nA = (int64_t)g->n * g->A;
+    struct V { const char *name; const float *p; int64_t cnt; };
+    const V vs[] = {{"a_new", d.anew, nA}, {"mu", d.mu, nA}, {"log_std", d.ls, nA}, {"a_next", d.a2, nA},
+                    {"log_pi", d.logpi, n}, {"log_pi_next", d.logpi2, n}, {"q1", d.QO[0], n}, {"q2", d.QO[1], n},
+                    {"q1_new", d.QO[0] + n, n}, {"q2_new", d.QO[1] + n, n}, {"tq1", d.QO[2], n}, {"tq2", d.QO[3], n},
+                    {"q_target", d.y, n}, {"diag_trace", d.diag_trace, (int64_t)DIAG_TRACE_CAP * SAC_DIAG_N}};
+    for (const V &v : vs)
+        if (nm == v.name) {
+            const int64_t cnt = nm == "diag_trace" && cap < v.cnt ? cap : v.cnt;
+            if (cap < cnt) { sac::set_error("buffer too small"); return -2; }
+            if (hipMemcpyAsync(out, v.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+                hipStreamSynchronize(t->stream) != hipSuccess) { sac::set_error("copy failed in sac_debug_fetch"); return -1; }
+            return cnt;
+        }
+    const char *gn[3] = {"g_policy", "g_qf1", "g_qf2"};
+    for (int i = 0; i < 3; ++i)
+        if (nm == gn[i]) {
+            if (cap < g->net[i].n) { sac::set_error("buffer too small"); return -2; }
+            if (gen_download(t, i, g->net[i].G, out)) return -1;
+            return g->net[i].n;
+        }
+    sac::set_error("unknown debug tensor '%s'", nm.c_str());
+    return -2;
+}
+
+}  // namespace

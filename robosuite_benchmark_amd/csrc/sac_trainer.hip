@@ -1694,6 +1694,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 
 #include "sac_fused.h"
 #include "sac_chain.h"
+#include "sac_general.h"
 
 }  // namespace sac
 
@@ -1701,6 +1702,8 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
 // host side
 // ==========================================================================================
 using namespace sac;
+
+struct sac_general;
 
 struct sac_trainer {
     sac_config_t cfg{};
@@ -1766,7 +1769,12 @@ struct sac_trainer {
     void (*chaink)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_chain = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
+    // hidden_sizes beyond two layers of <= 256 units: the general step (sac_general.h); everything above that belongs to
+    // the fused kernels stays unused
+    sac_general *gen = nullptr;
 };
+
+#include "sac_general_host.h"
 
 namespace {
 
@@ -1924,6 +1932,7 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
 // between the launches (profiling pass only)
 
 int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr, bool want_stats = false) {
+    if (t->gen) return gen_launch_step(t, S, SL, j);
     if (t->algo == 1) return launch_step_td3(t, S, SL, j, want_stats);
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
@@ -2133,9 +2142,40 @@ static int trainer_create(sac_trainer_t **out, const sac_config_t *cfg, const td
     return 0;
 }
 
-static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_config_t *td3) {
+// what every kind of trainer has: stream, events, the pinned diagnostics
+static int trainer_common_init(sac_trainer *t, const sac_config_t *cfg) {
     t->cfg = *cfg; t->device = cfg->device;
     t->Bt = cfg->batch; t->B = round_up(cfg->batch, RB); t->O = cfg->obs_dim; t->A = cfg->act_dim;
+    SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    sac::stream_register(t->stream);
+    for (auto &e : t->thr_ev) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
+    for (auto &e : t->ev_tm) SAC_HIP(hipEventCreate(&e));
+    for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // first[32] | last[32] of the diagnostics live in MAPPED PINNED HOST memory: the one diagnostics workgroup of a step
+    // writes its ~30 floats straight over the link, and a caller reads them after the stream has drained without a
+    // device-to-host copy in its call (that copy was ~10 us of every sac_train_loop / sac_step)
+    SAC_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_diag), sizeof(float) * 2 * SAC_DIAG_N, hipHostMallocMapped));
+    memset(t->h_diag, 0, sizeof(float) * 2 * SAC_DIAG_N);
+    SAC_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&t->d_diag_host), t->h_diag, 0));
+    return 0;
+}
+
+// every event is recorded once at creation: the runtime sets an event's signal up at its first record, which otherwise
+// happens inside the first loop that is long enough to use it (a 20-step call behind a 5-step one: +40 us)
+static int trainer_prime_events(sac_trainer *t) {
+    hipStream_t s = t->stream;
+    for (auto &e : t->ev) SAC_HIP(hipEventRecord(e, s));
+    for (auto &e : t->ev_tm) SAC_HIP(hipEventRecord(e, s));
+    for (auto &e : t->ev_ready) SAC_HIP(hipEventRecord(e, s));
+    for (auto &e : t->ev_done) SAC_HIP(hipEventRecord(e, s));
+    SAC_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_config_t *td3) {
+    if (trainer_common_init(t, cfg)) return -1;
     t->algo = td3 ? 1 : 0;
     for (int i = 0; i < 2; ++i) {
         t->HP[i] = cfg->policy_hidden[i] ? cfg->policy_hidden[i] : cfg->hidden;
@@ -2151,19 +2191,6 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4) && ((v * t->NB) % 2 == 0)) t->SP = v;
     }
-    SAC_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    sac::stream_register(t->stream);
-    for (auto &e : t->thr_ev) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : t->ev) SAC_HIP(hipEventCreate(&e));
-    for (auto &e : t->ev_tm) SAC_HIP(hipEventCreate(&e));
-    for (auto &e : t->ev_ready) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : t->ev_done) SAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // first[32] | last[32] of the diagnostics live in MAPPED PINNED HOST memory: the one diagnostics workgroup of a step
-    // writes its ~30 floats straight over the link, and a caller reads them after the stream has drained without a
-    // device-to-host copy in its call (that copy was ~10 us of every sac_train_loop / sac_step)
-    SAC_HIP(hipHostMalloc(reinterpret_cast<void **>(&t->h_diag), sizeof(float) * 2 * SAC_DIAG_N, hipHostMallocMapped));
-    memset(t->h_diag, 0, sizeof(float) * 2 * SAC_DIAG_N);
-    SAC_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&t->d_diag_host), t->h_diag, 0));
     hipStream_t s = t->stream;
     const int B = t->B;
 
@@ -2378,13 +2405,50 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_fb));
     }
     SAC_REQUIRE(t->lds_fb <= 160 * 1024 - 512, "observation too wide for the LDS row-block budget (obs_dim=%d)", t->O);
-    // every event is recorded once here: the runtime sets an event's signal up at its first record, which otherwise
-    // happens inside the first loop that is long enough to use it (a 20-step call behind a 5-step one: +40 us)
-    for (auto &e : t->ev) SAC_HIP(hipEventRecord(e, s));
-    for (auto &e : t->ev_tm) SAC_HIP(hipEventRecord(e, s));
-    for (auto &e : t->ev_ready) SAC_HIP(hipEventRecord(e, s));
-    for (auto &e : t->ev_done) SAC_HIP(hipEventRecord(e, s));
-    SAC_HIP(hipStreamSynchronize(s));
+    return trainer_prime_events(t);
+}
+
+// hidden_sizes of any depth (sac_hip.h): shapes the fused kernels carry -- two hidden layers of at most 256 units per
+// family -- get them; everything else gets the general step (sac_general.h).  SAC_GENERAL=1 in the environment selects
+// the general step for every shape (cross-checks).
+int sac_trainer_create_mlp(sac_trainer_t **out, const sac_config_t *cfg, const int32_t *policy_hidden, int32_t n_policy_hidden,
+                           const int32_t *qf_hidden, int32_t n_qf_hidden) {
+    SAC_REQUIRE(out && cfg && policy_hidden && qf_hidden, "null argument to sac_trainer_create_mlp");
+    *out = nullptr;
+    SAC_REQUIRE(n_policy_hidden >= 1 && n_policy_hidden < gen::GMAXL && n_qf_hidden >= 1 && n_qf_hidden < gen::GMAXL,
+                "%d / %d hidden layers unsupported: 1..%d per network", n_policy_hidden, n_qf_hidden, gen::GMAXL - 1);
+    bool fits = n_policy_hidden == 2 && n_qf_hidden == 2;
+    for (int i = 0; i < n_policy_hidden; ++i) {
+        SAC_REQUIRE(policy_hidden[i] >= 1 && policy_hidden[i] <= 4096, "policy hidden size %d unsupported (1..4096)", policy_hidden[i]);
+        fits = fits && policy_hidden[i] <= H;
+    }
+    for (int i = 0; i < n_qf_hidden; ++i) {
+        SAC_REQUIRE(qf_hidden[i] >= 1 && qf_hidden[i] <= 4096, "qf hidden size %d unsupported (1..4096)", qf_hidden[i]);
+        fits = fits && qf_hidden[i] <= H;
+    }
+    const char *force = getenv("SAC_GENERAL");
+    if (fits && !(force && atoi(force) == 1)) {
+        sac_config_t c = *cfg;
+        for (int i = 0; i < 2; ++i) { c.policy_hidden[i] = policy_hidden[i]; c.qf_hidden[i] = qf_hidden[i]; }
+        return sac_trainer_create(out, &c);
+    }
+    SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
+    SAC_REQUIRE(cfg->obs_dim > 0 && cfg->act_dim > 0 && cfg->act_dim <= 16,
+                "unsupported dims obs=%d act=%d (act_dim must be in 1..16)", cfg->obs_dim, cfg->act_dim);
+    SAC_REQUIRE(cfg->obs_dim <= 496, "obs_dim %d unsupported (the minibatch slots hold cat(obs, act) rows of at most 512 columns)",
+                cfg->obs_dim);
+    SAC_REQUIRE(cfg->batch > 0, "batch size %d must be positive", cfg->batch);
+    SAC_REQUIRE(cfg->target_update_period > 0, "target_update_period must be positive");
+    SAC_HIP(hipSetDevice(cfg->device));
+    sac_trainer *t = new sac_trainer();
+    int hp[gen::GMAXL], hq[gen::GMAXL];
+    for (int i = 0; i < n_policy_hidden; ++i) hp[i] = policy_hidden[i];
+    for (int i = 0; i < n_qf_hidden; ++i) hq[i] = qf_hidden[i];
+    if (trainer_common_init(t, cfg) || gen_build(t, hp, n_policy_hidden, hq, n_qf_hidden) || trainer_prime_events(t)) {
+        sac_trainer_destroy(t);
+        return -1;
+    }
+    *out = t;
     return 0;
 }
 
@@ -2399,6 +2463,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
         if (G.last == t->stream) G.last = nullptr;
     }
     (void)hipFree(t->arena);
+    gen_destroy(t->gen);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->h_diag) (void)hipHostFree(t->h_diag);
     for (auto &e : t->ev) if (e) (void)hipEventDestroy(e);
@@ -2413,6 +2478,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
 
 int64_t sac_param_count(const sac_trainer_t *t, int net) {
     if (!t || net < 0 || net > (t->algo == 1 ? 5 : 4)) return -1;
+    if (t->gen) return t->gen->net[net].n;
     return flat_count(flat_map(t, net));
 }
 
@@ -2460,6 +2526,7 @@ int sac_set_params(sac_trainer_t *t, int net, const float *flat, int64_t n) {
                 (long long)sac_param_count(t, net), (long long)n);
     SAC_HIP(hipSetDevice(t->device));
     t->mirror_valid = false;
+    if (t->gen) return gen_upload(t, net, flat, t->gen->net[net].P);
     return upload_padded(t, net, flat, t->net[net].P, net < 3 ? t->net[net].PT : nullptr);
 }
 
@@ -2468,6 +2535,7 @@ int sac_get_params(sac_trainer_t *t, int net, float *flat, int64_t n) {
     SAC_REQUIRE(n == sac_param_count(t, net), "net %d holds %lld parameters, buffer has %lld", net,
                 (long long)sac_param_count(t, net), (long long)n);
     SAC_HIP(hipSetDevice(t->device));
+    if (t->gen) return gen_download(t, net, t->gen->net[net].P, flat);
     return download_padded(t, net, t->net[net].P, flat);
 }
 
@@ -2475,6 +2543,7 @@ int sac_set_opt_state(sac_trainer_t *t, int net, const float *m, const float *v,
     SAC_REQUIRE(t && m && v && net >= 0 && net <= 2, "bad arguments to sac_set_opt_state (trained nets are 0..2)");
     SAC_REQUIRE(n == sac_param_count(t, net), "size mismatch in sac_set_opt_state");
     SAC_HIP(hipSetDevice(t->device));
+    if (t->gen) return gen_upload(t, net, m, t->gen->net[net].M) || gen_upload(t, net, v, t->gen->net[net].V) ? -1 : 0;
     if (upload_padded(t, net, m, t->net[net].M, t->net[net].MT)) return -1;
     return upload_padded(t, net, v, t->net[net].V, t->net[net].VT);
 }
@@ -2483,6 +2552,7 @@ int sac_get_opt_state(sac_trainer_t *t, int net, float *m, float *v, int64_t n) 
     SAC_REQUIRE(t && m && v && net >= 0 && net <= 2, "bad arguments to sac_get_opt_state (trained nets are 0..2)");
     SAC_REQUIRE(n == sac_param_count(t, net), "size mismatch in sac_get_opt_state");
     SAC_HIP(hipSetDevice(t->device));
+    if (t->gen) return gen_download(t, net, t->gen->net[net].M, m) || gen_download(t, net, t->gen->net[net].V, v) ? -1 : 0;
     if (download_padded(t, net, t->net[net].M, m, t->net[net].MT)) return -1;
     return download_padded(t, net, t->net[net].V, v, t->net[net].VT);
 }
@@ -2895,7 +2965,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float *di
 
 int sac_profile_loop(sac_trainer_t *t, sac_buffer_t *b, int64_t n_steps, float out_ms[9]) {
     SAC_REQUIRE(t && b && n_steps > 0 && n_steps <= 4096 && out_ms, "bad arguments to sac_profile_loop");
-    SAC_REQUIRE(t->algo == 0, "sac_profile_loop instruments the SAC step only");
+    SAC_REQUIRE(t->algo == 0 && !t->gen, "sac_profile_loop instruments the SAC step of the fused kernels only");
     SAC_REQUIRE(b->device == t->device && b->O == t->O && b->A == t->A, "buffer does not match trainer");
     SAC_HIP(hipSetDevice(t->device));
     hipStream_t s = t->stream;
@@ -2992,7 +3062,7 @@ int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
 
 // 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step
 int sac_trainer_is_fused(const sac_trainer_t *t) { return (t && t->fused) ? 1 : 0; }
-int sac_trainer_step_kind(const sac_trainer_t *t) { return !t ? -1 : (t->fused ? 1 : (t->chain ? 2 : 0)); }
+int sac_trainer_step_kind(const sac_trainer_t *t) { return !t ? -1 : (t->gen ? 3 : (t->fused ? 1 : (t->chain ? 2 : 0))); }
 
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms) {
     SAC_REQUIRE(t, "null trainer");
@@ -3014,6 +3084,7 @@ int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float 
 int64_t sac_debug_fetch(sac_trainer_t *t, const char *name, float *out, int64_t cap) {
     if (!t || !name || !out) { sac::set_error("bad arguments to sac_debug_fetch"); return -2; }
     if (hipSetDevice(t->device) != hipSuccess) { sac::set_error("hipSetDevice failed"); return -1; }
+    if (t->gen) return gen_debug_fetch(t, std::string(name), out, cap);
     const int B = t->B, A = t->A;
     const Dev &d = t->dev;
     const std::string nm(name);
@@ -3087,21 +3158,30 @@ int sac_policy_act(sac_trainer_t *t, const float *obs, int deterministic, const 
     SAC_REQUIRE(deterministic || eps || t->algo == 1, "stochastic acting needs the N(0,1) draw (eps)");
     if (t->algo == 1) deterministic = 1;        // TanhMlpPolicy: tanh(last_fc); exploration noise is the caller's strategy
     if (!t->mirror_valid && sac_policy_mirror(t)) return -1;
-    const int O = t->O, A = t->A, H1 = t->HP[0], H2 = t->HP[1];
+    const int O = t->O, A = t->A;
+    int hs[gen::GMAXL], nh = 2;
+    hs[0] = t->HP[0]; hs[1] = t->HP[1];
+    if (t->gen) { nh = t->gen->Lp; for (int i = 0; i < nh; ++i) hs[i] = t->gen->hp[i]; }
+    // the flat vector: per hidden layer W [out][in] then b; last_fc (mean); last_fc_log_std (absent for TD3)
     const float *p = t->h_policy.data();
-    const float *W0 = p, *b0 = W0 + (size_t)H1 * O, *W1 = b0 + H1, *b1 = W1 + (size_t)H2 * H1;
-    const float *Wm = b1 + H2, *bm = Wm + (size_t)A * H2, *Ws = bm + A, *bs = Ws + (size_t)A * H2;
-    float h1[H], h2[H];
-    for (int n = 0; n < H1; ++n) {
-        float s = b0[n];
-        for (int k = 0; k < O; ++k) s += W0[(size_t)n * O + k] * obs[k];
-        h1[n] = s > 0.f ? s : 0.f;
+    thread_local std::vector<float> hin, hout;
+    hin.assign(obs, obs + O);
+    int dprev = O;
+    for (int l = 0; l < nh; ++l) {
+        const float *W = p, *b = W + (size_t)hs[l] * dprev;
+        hout.resize((size_t)hs[l]);
+        for (int n = 0; n < hs[l]; ++n) {
+            float s = b[n];
+            for (int k = 0; k < dprev; ++k) s += W[(size_t)n * dprev + k] * hin[(size_t)k];
+            hout[(size_t)n] = s > 0.f ? s : 0.f;
+        }
+        hin.swap(hout);
+        p = b + hs[l];
+        dprev = hs[l];
     }
-    for (int n = 0; n < H2; ++n) {
-        float s = b1[n];
-        for (int k = 0; k < H1; ++k) s += W1[(size_t)n * H1 + k] * h1[k];
-        h2[n] = s > 0.f ? s : 0.f;
-    }
+    const int H2 = dprev;
+    const float *h2 = hin.data();
+    const float *Wm = p, *bm = Wm + (size_t)A * H2, *Ws = bm + A, *bs = Ws + (size_t)A * H2;
     for (int a = 0; a < A; ++a) {
         float m = bm[a], ls = 0.f;
         for (int k = 0; k < H2; ++k) m += Wm[(size_t)a * H2 + k] * h2[k];

@@ -53,21 +53,26 @@ class SACTrainer:
     NETS = NET_IDS                           # name -> C net id (TD3Trainer adds target_policy)
 
     def _new_handle(self, batch):
+        hp, hq = self._hidden("policy"), self._hidden("qf1")
         cfg = SacConfig(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale, self.policy_lr,
                         self.qf_lr, self.soft_target_tau, self.target_update_period,
                         int(self.use_automatic_entropy_tuning), self.target_entropy, self.noise_seed, self.device, 0,
-                        (C.c_int32 * 2)(*self._hidden("policy")), (C.c_int32 * 2)(*self._hidden("qf1")))
+                        (C.c_int32 * 2)(0, 0), (C.c_int32 * 2)(0, 0))
         h = C.c_void_p()
-        _lib.check(self._lib.sac_trainer_create(C.byref(h), C.byref(cfg)), "sac_trainer_create")
+        _lib.check(self._lib.sac_trainer_create_mlp(C.byref(h), C.byref(cfg), (C.c_int32 * len(hp))(*hp), len(hp),
+                                                    (C.c_int32 * len(hq))(*hq), len(hq)), "sac_trainer_create_mlp")
         return h
 
+    MAX_HIDDEN_LAYERS, MAX_HIDDEN_UNITS = 7, 4096
+
     def _hidden(self, net):
-        """variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'] of a network family: two layers of at most 256 units (the
-        kernels' 256-wide layers carry narrower ones exactly, as zero rows / columns)."""
+        """variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'] of a network family (arguments.py:98,104).  Two layers of at
+        most 256 units (every shipped variant.json: [256, 256]) run on the fused kernels -- narrower layers exactly, as
+        zero rows / columns of the 256-wide ones; any other depth / width runs the library's general step."""
         hs = [int(h) for h in getattr(self, net).hidden_sizes]
-        if len(hs) != 2 or not all(1 <= h <= 256 for h in hs):
-            raise RuntimeError(f"hidden_sizes {hs} unsupported: the HIP path implements two hidden layers of at most 256 "
-                               "units each (every shipped variant.json uses [256, 256])")
+        if not 1 <= len(hs) <= self.MAX_HIDDEN_LAYERS or not all(1 <= h <= self.MAX_HIDDEN_UNITS for h in hs):
+            raise RuntimeError(f"hidden_sizes {hs} unsupported: 1..{self.MAX_HIDDEN_LAYERS} hidden layers of "
+                               f"1..{self.MAX_HIDDEN_UNITS} units")
         return hs
 
     def _create(self, batch):
@@ -217,7 +222,8 @@ class SACTrainer:
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
     def fused_mode(self):
-        """0: four launches per step; 1: the fused step, k_abc + k_dw_adam; 2: k_chain + k_bwd + k_dw_adam (batch >= 1024)."""
+        """0: four launches per step; 1: the fused step, k_abc + k_dw_adam; 2: k_chain + k_bwd + k_dw_adam (batch >= 1024);
+        3: the general step (hidden_sizes beyond two layers of at most 256 units)."""
         return int(self._lib.sac_trainer_step_kind(self._h)) if self._h is not None else 0
 
     def is_fused(self):

@@ -34,6 +34,14 @@ class TD3Trainer(SACTrainer):
                          use_automatic_entropy_tuning=False, target_entropy=0.0, batch_size=batch_size,
                          noise_seed=noise_seed, device=device)
 
+    def _hidden(self, net):
+        """TD3 runs on the fused kernels only: two hidden layers of at most 256 units (rlkit_utils.py:108-117 builds them so)."""
+        hs = [int(h) for h in getattr(self, net).hidden_sizes]
+        if len(hs) != 2 or not all(1 <= h <= 256 for h in hs):
+            raise RuntimeError(f"hidden_sizes {hs} unsupported for TD3: two hidden layers of at most 256 units each "
+                               "(SACTrainer takes any depth / width)")
+        return hs
+
     def _new_handle(self, batch):
         cfg = Td3Config(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale,
                         self.policy_learning_rate, self.qf_learning_rate, self.tau, self.target_policy_noise,

@@ -1,0 +1,132 @@
+"""GPU parity of the GENERAL step (csrc/sac_general.h): hidden_sizes of any depth / width
+(/root/reference/util/arguments.py:98,104 -> FlattenMlp / TanhGaussianPolicy, rlkit_utils.py:64-97) against the CPU oracle
+built at the same sizes -- same tolerance as the fused kernels (tests/test_gpu_sac_step.py) -- and against the fused
+kernels themselves on a shape both can run.  Parity: unpinned beyond the oracle (no shipped run uses other sizes than
+[256, 256])."""
+import pickle
+
+import numpy as np
+import pytest
+
+from tests.helpers import TASK_DIMS, flat_of, make_pair, rel_err, synth_transitions
+from tests.test_gpu_sac_step import TOL, batch_and_noise, check_diag, scale_err
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [((512, 512), None, "Lift", 256), ((256, 256, 256), None, "Door", 128), ((256,), (300,), "Lift", 100),
+          ((64, 64, 64, 64), (400, 300), "TwoArmLift", 64), ((1024, 1024), (1024, 1024), "Lift", 32),
+          ((300, 7, 129), (5, 600, 33), "Wipe", 48), ((400, 300), (400, 300), "Stack", 1), ((256, 256), (256, 256, 64), "Lift", 256)]
+
+
+@pytest.mark.parametrize("hidden,hidden_q,task,B", SHAPES)
+def test_steps_against_the_oracle(hidden, hidden_q, task, B):
+    O, A = TASK_DIMS[task]
+    oracle, hip = make_pair(O, A, B, seed=11, hidden=hidden, hidden_q=hidden_q)
+    assert hip.fused_mode() == 3
+    for s_ in range(5):
+        np_batch, eps = batch_and_noise(B, O, A, seed=700 + s_, term_frac=0.05)
+        want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"], np_batch["terminals"],
+                           np_batch["next_observations"], *eps)
+        diag = hip.train(np_batch, eps=eps)
+        check_diag(diag, want, tol=1e-4 if s_ else TOL)
+        if s_:
+            continue
+        L = oracle.last
+        for name, ref in (("a_new", L["a_new"]), ("mu", L["mu"]), ("log_std", L["log_std"]), ("a_next", L["a2"])):
+            assert scale_err(hip.debug_fetch(name, B * A), ref.detach().numpy().ravel()) < 2e-5, name
+        for name, ref in (("log_pi", L["log_pi"]), ("log_pi_next", L["log_pi2"]), ("q1", L["q1"]), ("q2", L["q2"]),
+                          ("q_target", L["y"]), ("q1_new", L["q1_new"]), ("q2_new", L["q2_new"])):
+            assert rel_err(hip.debug_fetch(name, B), ref.detach().numpy().ravel()) < 2e-5, name
+        for key in ("g_policy", "g_qf1", "g_qf2"):
+            ws, bs = L[key][:len(L[key]) // 2], L[key][len(L[key]) // 2:]
+            ref = np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(ws, bs)])
+            assert scale_err(hip.debug_fetch(key, ref.size), ref) < 5e-5, key
+    # parameters, Adam moments and the entropy coefficient after five steps.  Where a gradient is ~0 Adam's early steps move
+    # a weight by ~lr whatever its sign: compare at a fraction of what five steps can move
+    st, after = hip.state_dict(), oracle.export_nets()
+    for name in ("policy", "qf1", "qf2", "target_qf1", "target_qf2"):
+        ref = flat_of(after[name])
+        assert st["params"][name].shape == ref.shape
+        lr = 1e-3 if name == "policy" else 5e-4
+        d = np.abs(st["params"][name] - ref)
+        assert np.quantile(d, 0.999) < 0.05 * lr and d.max() < 10 * lr, (name, d.max(), np.quantile(d, 0.999))
+    assert abs(st["scalars"][0] - float(oracle.log_alpha.detach())) < 1e-6
+    assert st["scalars"][3] == st["scalars"][4] == 5
+
+
+def test_the_general_step_and_the_fused_kernels_agree_on_a_shape_both_run(monkeypatch):
+    """SAC_GENERAL=1 sends [256, 256] through the general step: same parameters, same batches, the same device noise
+    stream (same counter-based generator, same indexing) -- two implementations of one step, within fp32 round-off."""
+    from tests.test_gpu_fused_step import _buffer
+    O, A, B = TASK_DIMS["Lift"] + (256,)
+    _, fast = make_pair(O, A, B, seed=4, noise_seed=9)
+    monkeypatch.setenv("SAC_GENERAL", "1")
+    _, gen = make_pair(O, A, B, seed=4, noise_seed=9)
+    monkeypatch.delenv("SAC_GENERAL")
+    assert fast.fused_mode() == 1 and gen.fused_mode() == 3
+    bufs = [_buffer(4000, O, A, 1), _buffer(4000, O, A, 1)]
+    for b in bufs:
+        b.seed(5)
+    fa, la = fast.train_loop(bufs[0], 10, batch_size=B)
+    fb, lb = gen.train_loop(bufs[1], 10, batch_size=B)
+    assert np.allclose(fa, fb, rtol=2e-5, atol=2e-5), np.abs(fa - fb).max()
+    assert np.allclose(la, lb, rtol=2e-4, atol=2e-4), np.abs(la - lb).max()
+    assert np.array_equal(bufs[0].rng_state()[0], bufs[1].rng_state()[0])
+    pa, pb = fast.state_dict()["params"], gen.state_dict()["params"]
+    for k in pa:
+        d = np.abs(pa[k] - pb[k])
+        assert np.quantile(d, 0.999) < 1e-4 and d.max() < 1e-2, (k, d.max())
+
+
+def test_loop_stepwise_device_batches_and_restored_state_are_one_trajectory():
+    """The general step behind every entry point: sac_train_loop == random_batch + train on device batches == host batches
+    of the same indices (device noise), bit for bit; a state_dict / pickle round trip continues the same trajectory."""
+    from tests.test_gpu_fused_step import _buffer
+    O, A, B, hidden = 46, 7, 96, (320, 200, 64)
+    trainers = [make_pair(O, A, B, seed=6, noise_seed=2, hidden=hidden)[1] for _ in range(3)]
+    bufs = [_buffer(3000, O, A, 2) for _ in range(3)]
+    for b in bufs:
+        b.seed(13)
+    n = 23
+    _, last = trainers[0].train_loop(bufs[0], n, batch_size=B)
+    for i in range(n):
+        trainers[1].train(bufs[1].random_batch(B))
+    for i in range(n):
+        batch = bufs[2].random_batch(B)
+        host = {k: np.array(batch[k]) for k in ("observations", "actions", "rewards", "terminals", "next_observations")}
+        d2 = trainers[2].train(host)
+    trainers[1]._need_to_update_eval_statistics = True
+    sa, sb, sc = (t.state_dict() for t in trainers)
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]) and np.array_equal(sa["params"][k], sc["params"][k]), k
+    for k in sa["opt"]:
+        for j in range(2):
+            assert np.array_equal(sa["opt"][k][j], sb["opt"][k][j]) and np.array_equal(sa["opt"][k][j], sc["opt"][k][j]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"]) and np.array_equal(sa["scalars"], sc["scalars"])
+    assert np.array_equal(last, d2)
+    # restore into a fresh trainer (pickle of the whole trainer) and continue: same as continuing the original
+    clone = pickle.loads(pickle.dumps(trainers[0]))
+    b0, b1 = _buffer(3000, O, A, 2), _buffer(3000, O, A, 2)
+    b0.seed(3); b1.seed(3)
+    _, la = trainers[0].train_loop(b0, 7, batch_size=B)
+    _, lb = clone.train_loop(b1, 7, batch_size=B)
+    assert clone.fused_mode() == 3 and np.array_equal(la, lb)
+
+
+def test_acting_through_a_general_trainer():
+    """policy.get_action on a deeper policy: the library's acting entry (host forward of the mirrored weights) == the
+    holder's own numpy forward of the same weights."""
+    O, A, B = 42, 7, 64
+    _, hip = make_pair(O, A, B, seed=8, hidden=(128, 96, 80), hidden_q=(300,))
+    np_batch, eps = batch_and_noise(B, O, A, seed=3)
+    hip.train(np_batch, eps=eps)
+    pol = hip.policy
+    obs = np_batch["observations"][:5]
+    got = np.stack([pol.get_action(o, deterministic=True)[0] for o in obs])
+    hip.sync_networks_to_host()
+    mean, _ = pol._trunk(obs)
+    assert np.allclose(got, np.tanh(mean), rtol=1e-5, atol=1e-6)
+    # a pickled holder is a self-contained host network of the same shape
+    back = pickle.loads(pickle.dumps(pol))
+    assert [w.shape for w, _ in back.layers.values()] == [(128, O), (96, 128), (80, 96), (A, 80), (A, 80)]
+    assert np.allclose(back.get_actions(obs, deterministic=True), got, rtol=1e-5, atol=1e-6)

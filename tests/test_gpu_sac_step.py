@@ -207,7 +207,7 @@ def test_errors_are_reported_not_fatal():
     qs = [FlattenMlp([256, 256], 1, 13) for _ in range(4)]
     with pytest.raises(RuntimeError, match="must be positive"):
         SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=0)
-    for bad in ([512, 512], [256, 256, 256], [256]):             # wider or deeper than the kernels' two 256-wide layers
+    for bad in ([], [64] * 8, [5000, 64]):                        # no hidden layer; more than seven; wider than 4096
         pol2 = TanhGaussianPolicy(bad, 10, 3)
         with pytest.raises(RuntimeError, match="hidden_sizes"):
             SACTrainer(policy=pol2, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], batch_size=64)
