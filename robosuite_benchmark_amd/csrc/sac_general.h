@@ -4,20 +4,19 @@
 // inside namespace sac (device part); the host part is sac_general_host.h.
 //
 // Same step, same order, as a sequence of launches instead of fused row-block kernels:
-//   k_g_prep     rows of the slot -> the two input matrices (policy: [obs ; next_obs], Q nets: [obs|act ; obs|. ; next_obs|.])
 //   k_g_gemm     ONE kernel for every matrix product of the step -- layer forward (X W^T + b, relu), backward through a
 //                layer (dY W, masked by the relu of the layer below), weight gradient (dY^T X, the bias gradient as an
 //                extra column of ones) -- as a table of jobs per launch: a launch carries every network's job of one
 //                stage (Q1, Q2 and both targets' layer l are ONE launch).  64 x 64 output tiles, fp32 MFMA 16x16x4,
 //                operands staged through LDS with generic strides.
-//   k_g_head     tanh-Gaussian head on both policy passes (rsample, log-prob)
-//   k_g_alpha    mean(log_pi) -> Adam step on log_alpha
+//   k_g_head     tanh-Gaussian head on both policy passes (rsample, log-prob); the Q nets' input rows
+//                [obs|act ; obs|a_new ; next_obs|a']; its last workgroup: mean(log_pi) -> Adam step on log_alpha
 //   k_g_loss     min over the twin nets, Bellman target, the loss gradients of the four Q passes that have one
 //   k_g_polgrad  head gradient of the reparameterised actor loss
-//   k_g_adam     Adam on every trained parameter + Polyak average of the targets (flat vectors)
-//   k_g_diag     the diagnostics vector
+//   k_g_adam     Adam on every trained parameter + Polyak average of the targets (flat vectors); one workgroup of it
+//                computes the diagnostics vector
 // Weights live in nn.Linear layout (W [out][in] row-major, then b), activations row-major [row][feature]; rows = the
-// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 11 launches per step (19 for two hidden layers): this path is for
+// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 8 launches per step (16 for two hidden layers): this path is for
 // shapes the reference can be configured with but no shipped variant uses -- the shipped ones take the fused kernels.
 #pragma once
 
@@ -35,11 +34,13 @@ struct GemmJob {
     const float *bias, *mask;
     float *c_ones;                  // ones_col: B gets a column n == N of ones, whose sums go here (c_ones[m]): a bias gradient
     long long sa_m, sa_r, sb_n, sb_r, ldc, ldmask;
+    long long a_off, b_off;         // a_slot / b_slot: the operand lives in the step's minibatch slot, at this offset (floats)
     int M, N, R;
-    int relu, ones_col, tiles_n, tile0, pad_;
+    int relu, ones_col, tiles_n, tile0, a_slot, b_slot, pad_;
 };
 struct GemmStage {                  // kernel argument: the jobs of one launch (device array) + their first tiles
     const GemmJob *jobs;
+    const float *S;                 // the step's minibatch slot
     int njobs, ntiles;
     int tile0[GMAXJ];
 };
@@ -52,9 +53,10 @@ struct GDev {
     int period, auto_alpha;
     unsigned long long noise_seed;
     Ctl *ctl;
-    float *XP, *XQ;                 // [2n][O], [3n][O + A]
+    float *XQ;                      // the Q nets' input rows [3n][O + A]
     const float *HD;                // head pre-activations [2n][2A]: mean | log-std
     float *mu, *ls, *ok, *epsv, *anew, *a2, *logpi, *logpi2;
+    unsigned *done;                 // workgroups of the head launch that have finished (the last one takes the entropy step)
     const float *QO[4];             // q1 [2n] (s,a | s,a_new), q2 [2n], target q1 [n], target q2 [n]
     float *DQ[2];                   // dL/dq of the critic rows | of the actor rows [2n]
     float *y, *qn;                  // Bellman target [n]; min Q(s, a_new) [n]
@@ -80,7 +82,11 @@ struct AdamArgs {
 // contiguous along the reduction, [r][row] otherwise: conflict-free writes either way -- and the next chunk's loads are in
 // flight while this one's 64 MFMAs per wave run.  The MFMA with index i of k-group (q, g) contracts r = 16 q + 4 g + i for
 // both operands, so an operand stored [row][r] is read with one 16-byte LDS load per four MFMAs.
+// A_RC / B_RC (compile time: the jobs of a launch share them): the operand is contiguous along the reduction -- forward
+// (true, true), backward through a layer (true, false), weight gradient (false, false).  Only the thread -> element map
+// and the LDS layout depend on it; the addresses always use the job's strides.
 constexpr int GK = 64;
+template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     __shared__ __attribute__((aligned(16))) float As[GT * GLD], Bs[GT * GLD];
     int li = 0;
@@ -94,11 +100,12 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
         for (int q = 0; q < (int)(sizeof(GemmJob) / 8); ++q) ud.w[q] = src[q];
     }
     const GemmJob &J = ud.J;
+    const float *const Ap = J.a_slot ? T.S + J.a_off : J.A, *const Bp = J.b_slot ? T.S + J.b_off : J.Bm;
     const int tile = (int)blockIdx.x - J.tile0;
     const int m0 = GT * (tile / J.tiles_n), n0 = GT * (tile % J.tiles_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int Neff = J.N + (J.ones_col ? 1 : 0);
-    const bool a_rc = (J.sa_r == 1), b_rc = (J.sb_r == 1);       // operand contiguous along the reduction?
+    constexpr bool a_rc = A_RC, b_rc = B_RC;
     // This thread's 16 elements of a chunk: fast coordinate `lane`, slow coordinates wave + 4 j (the row for an operand that is
     // contiguous along the reduction, else the reduction index).  Loads are UNCONDITIONAL from clamped indices -- a row or
     // column beyond the matrix repeats the last one (its products land in outputs that are never stored), the reduction's
@@ -118,21 +125,21 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     float xa[16], xb[16];
     auto fetch = [&](int s) {
         const int r0 = GK * s;
-        if (a_rc) {
-            const int ro = min(r0 + lane, J.R - 1);
+        if constexpr (a_rc) {
+            const int ro = min(r0 + lane, J.R - 1) * sa_r;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xa[j] = ld1g(J.A + (xoa[j] + ro));
+            for (int j = 0; j < 16; ++j) xa[j] = ld1g(Ap + (xoa[j] + ro));
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xa[j] = ld1g(J.A + (xoa[0] + min(r0 + wv + 4 * j, J.R - 1) * sa_r));
+            for (int j = 0; j < 16; ++j) xa[j] = ld1g(Ap + (xoa[0] + min(r0 + wv + 4 * j, J.R - 1) * sa_r));
         }
-        if (b_rc) {
-            const int ro = min(r0 + lane, J.R - 1);
+        if constexpr (b_rc) {
+            const int ro = min(r0 + lane, J.R - 1) * sb_r;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = ld1g(J.Bm + (xob[j] + ro));
+            for (int j = 0; j < 16; ++j) xb[j] = ld1g(Bp + (xob[j] + ro));
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = ld1g(J.Bm + (xob[0] + min(r0 + wv + 4 * j, J.R - 1) * sb_r));
+            for (int j = 0; j < 16; ++j) xb[j] = ld1g(Bp + (xob[0] + min(r0 + wv + 4 * j, J.R - 1) * sb_r));
         }
     };
     // behind the loads' arrival (in front of the LDS writes): the column of ones, the reduction's zero padding
@@ -163,12 +170,12 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a, b[4];
-            if (a_rc) a = ld4(As + (16 * wave + c) * GLD + 16 * q + 4 * g);
+            if constexpr (a_rc) a = ld4(As + (16 * wave + c) * GLD + 16 * q + 4 * g);
             else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = As[(16 * q + 4 * g + i) * GLD + 16 * wave + c];
             }
-            if (b_rc) {
+            if constexpr (b_rc) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) b[t] = ld4(Bs + (16 * t + c) * GLD + 16 * q + 4 * g);
             } else {
@@ -206,67 +213,72 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
 // ------------------------------------------------------------------------------------------
 // elementwise kernels
 // ------------------------------------------------------------------------------------------
-// np_to_pytorch_batch + the torch.cat of FlattenMlp: the slot's rows into the input matrices
-__global__ __launch_bounds__(256) void k_g_prep(GDev d, const float *__restrict__ S, SlotLayout SL) {
-    const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
-    const long long tot = (long long)n * (2 * O + A);
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
-        const int b = (int)(e / (2 * O + A)), k = (int)(e % (2 * O + A));
-        if (k < O) {
-            const float v = S[SL.off_obs + (long long)b * O + k];
-            d.XP[(long long)b * O + k] = v;
-            d.XQ[(long long)b * ldq + k] = v;
-            d.XQ[(long long)(n + b) * ldq + k] = v;
-        } else if (k < 2 * O) {
-            const float v = S[SL.off_nobs + (long long)b * O + (k - O)];
-            d.XP[(long long)(n + b) * O + (k - O)] = v;
-            d.XQ[(long long)(2 * n + b) * ldq + (k - O)] = v;
-        } else {
-            d.XQ[(long long)b * ldq + O + (k - 2 * O)] = S[SL.off_act + (long long)b * A + (k - 2 * O)];
-        }
-    }
-}
-
 // TanhGaussianPolicy.forward(reparameterize=True, return_log_prob=True) behind the head layer, both passes: one thread
-// per row (side 0: policy(s), side 1: policy(s')); the new actions go straight into the Q nets' input rows
-__global__ __launch_bounds__(256) void k_g_head(GDev d, StepArg sa) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= 2 * d.n) return;
-    const int n = d.n, A = d.A, side = r >= n ? 1 : 0, b = r - side * n;
-    const float *epp = side ? d.eps2 : d.eps1;
-    const float *hd = d.HD + (long long)r * 2 * A;
-    float lsum = 0.f;
-    for (int a = 0; a < A; ++a) {
-        const float mean = hd[a], raw = hd[A + a];
-        const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
-        const float stdv = expf(lstd);
-        const float eps = epp ? epp[(long long)b * A + a]
-                              : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(b * d.NI + a), side ? 1u : 0u);
-        const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));            // TanhNormal.rsample
-        const float act = tanhf(zz);
-        const float dd = __fsub_rn(zz, mean);                               // Normal.log_prob(z) - log(1 - a^2 + eps)
-        const float var = __fmul_rn(stdv, stdv);
-        const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
-        lsum += nlp - logf(1.0f - act * act + TANH_EPS);
-        const long long gi = (long long)b * A + a;
-        if (!side) {
-            d.mu[gi] = mean; d.ls[gi] = lstd; d.ok[gi] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.0f : 0.0f;
-            d.epsv[gi] = eps; d.anew[gi] = act;
-            d.XQ[(long long)(n + b) * d.ldq + d.O + a] = act;
-        } else {
-            d.a2[gi] = act;
-            d.XQ[(long long)(2 * n + b) * d.ldq + d.O + a] = act;
+// per row (side 0: policy(s), side 1: policy(s')).  The kernel also assembles the Q nets' input rows -- the torch.cat of
+// FlattenMlp: [obs|act ; obs|a_new ; next_obs|a'] -- and its LAST workgroup to finish takes the entropy step (SURVEY
+// Appendix A lines 4-6: alpha_loss = -mean(log_alpha (log_pi + H)), one Adam step on log_alpha, alpha = exp(.) post-step;
+// the sum runs in a fixed order).  Rows written by other workgroups are read back through agent-scope loads.
+__global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    {
+        const long long tot = (long long)n * (2 * O + A);
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+            const int b = (int)(e / (2 * O + A)), k = (int)(e % (2 * O + A));
+            if (k < O) {
+                const float v = S[SL.off_obs + (long long)b * O + k];
+                d.XQ[(long long)b * ldq + k] = v;
+                d.XQ[(long long)(n + b) * ldq + k] = v;
+            } else if (k < 2 * O) {
+                d.XQ[(long long)(2 * n + b) * ldq + (k - O)] = S[SL.off_nobs + (long long)b * O + (k - O)];
+            } else {
+                d.XQ[(long long)b * ldq + O + (k - 2 * O)] = S[SL.off_act + (long long)b * A + (k - 2 * O)];
+            }
         }
     }
-    (side ? d.logpi2 : d.logpi)[b] = lsum;
-}
-
-// SURVEY Appendix A lines 4-6: alpha_loss = -mean(log_alpha (log_pi + H)), one Adam step on log_alpha, alpha = exp(.)
-// (post-step).  One workgroup; the sum runs in a fixed order.
-__global__ __launch_bounds__(256) void k_g_alpha(GDev d, StepArg sa) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < 2 * n) {
+        const int side = r >= n ? 1 : 0, b = r - side * n;
+        const float *epp = side ? d.eps2 : d.eps1;
+        const float *hd = d.HD + (long long)r * 2 * A;
+        float lsum = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float mean = hd[a], raw = hd[A + a];
+            const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
+            const float stdv = expf(lstd);
+            const float eps = epp ? epp[(long long)b * A + a]
+                                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(b * d.NI + a), side ? 1u : 0u);
+            const float zz = __fadd_rn(mean, __fmul_rn(stdv, eps));            // TanhNormal.rsample
+            const float act = tanhf(zz);
+            const float dd = __fsub_rn(zz, mean);                               // Normal.log_prob(z) - log(1 - a^2 + eps)
+            const float var = __fmul_rn(stdv, stdv);
+            const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
+            lsum += nlp - logf(1.0f - act * act + TANH_EPS);
+            const long long gi = (long long)b * A + a;
+            if (!side) {
+                d.mu[gi] = mean; d.ls[gi] = lstd; d.ok[gi] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.0f : 0.0f;
+                d.epsv[gi] = eps; d.anew[gi] = act;
+                d.XQ[(long long)(n + b) * ldq + O + a] = act;
+            } else {
+                d.a2[gi] = act;
+                d.XQ[(long long)(2 * n + b) * ldq + O + a] = act;
+            }
+        }
+        st_sc1((side ? d.logpi2 : d.logpi) + b, lsum);
+    }
+    // ---- the last workgroup: mean(log_pi) -> the entropy coefficient ----
     __shared__ float red[256];
+    __shared__ unsigned am_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(d.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        am_last = (old == gridDim.x - 1) ? 1u : 0u;
+        if (am_last) __hip_atomic_store(d.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next step
+    }
+    __syncthreads();
+    if (!am_last) return;
     float s = 0.f;
-    for (int i = threadIdx.x; i < d.n; i += 256) s += d.logpi[i];
+    for (int i = threadIdx.x; i < n; i += 256) s += ld_sc1(d.logpi + i);
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -277,7 +289,7 @@ __global__ __launch_bounds__(256) void k_g_alpha(GDev d, StepArg sa) {
     Ctl *c = d.ctl;
     if (!d.auto_alpha) { c->alpha = 1.0f; c->alpha_loss = 0.0f; return; }
     const float la = c->log_alpha, m0 = c->a_m, v0 = c->a_v;
-    const float mean_lp = red[0] / (float)d.n + d.target_entropy;
+    const float mean_lp = red[0] / (float)n + d.target_entropy;
     const float gr = -mean_lp;
     const float m = m0 + ADAM_1MB1 * (gr - m0);
     const float v = v0 * ADAM_B2 + ADAM_1MB2 * gr * gr;
@@ -323,12 +335,16 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
     d.DHD[(long long)b * 2 * d.A + d.A + a] = dls;
 }
 
-// torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets
+__device__ void diag_block(const GDev &d, const StepArg &sa);
+
+// torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets; workgroup 0
+// computes the step's diagnostics instead (it reads nothing this launch writes)
 __global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) {
+    if (blockIdx.x == 0) { diag_block(d, sa); return; }
     const bool polyak = (sa.step_now % d.period) == 0;
     const float bc2s = (float)sa.bc2s;
     const long long tot = P.n[0] + P.n[1] + P.n[2];
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
+    for (long long e = (long long)(blockIdx.x - 1) * 256 + threadIdx.x; e < tot; e += (long long)(gridDim.x - 1) * 256) {
         const int k = e < P.n[0] ? 0 : (e < P.n[0] + P.n[1] ? 1 : 2);
         const long long i = e - (k > 0 ? P.n[0] : 0) - (k > 1 ? P.n[1] : 0);
         float p = P.P[k][i], m = P.M[k][i], v = P.V[k][i];
@@ -339,7 +355,7 @@ __global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) 
 }
 
 // the diagnostics vector (SURVEY Appendix A line 17); one workgroup, sums in double
-__global__ __launch_bounds__(256) void k_g_diag(GDev d, StepArg sa) {
+__device__ void diag_block(const GDev &d, const StepArg &sa) {
     constexpr int NQ = 28;
     // 0-3 q1 (sum, sum sq, max, min)  4-7 q2  8-11 y  12-15 log_pi  16 (q1-y)^2  17 (q2-y)^2  18 log_pi - q_new
     // 19 alpha log_pi - q_new  20-23 mu  24-27 log_std

@@ -10,8 +10,8 @@ struct GenNet {
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     std::vector<long long> perm;            // flat (sac_get_params) index -> index in the device vector
 };
-struct GenStage { int kind = 0; size_t base = 0; gen::GemmStage gs{}; };   // kind 0: a k_g_gemm launch; else see launch
-enum { GS_GEMM = 0, GS_PREP, GS_HEAD, GS_ALPHA, GS_LOSS, GS_POLGRAD, GS_ADAM, GS_DIAG };
+struct GenStage { int kind = 0, mode = 0; size_t base = 0; gen::GemmStage gs{}; };   // mode: 0 forward, 1 backward, 2 weight gradients   // kind 0: a k_g_gemm launch; else see launch
+enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_ADAM };
 
 struct sac_general {
     int n = 0, O = 0, A = 0, Lp = 0, Lq = 0;
@@ -120,7 +120,7 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     gen::GDev &d = g->dev;
     float *PH[gen::GMAXL] = {}, *dPZ[gen::GMAXL] = {}, *HD = nullptr;
     float *QH[2][gen::GMAXL] = {}, *TH[2][gen::GMAXL] = {}, *dQZ[2][gen::GMAXL] = {}, *QO[4] = {}, *DA[2] = {};
-    bump.want(&d.XP, 2LL * n * O); bump.want(&d.XQ, 3LL * n * ldq);
+    bump.want(&d.XQ, 3LL * n * ldq); bump.want(&d.done, 64);
     for (int l = 0; l < Lp; ++l) { bump.want(&PH[l], 2LL * n * hp[l]); bump.want(&dPZ[l], (long long)n * hp[l]); }
     bump.want(&HD, 2LL * n * 2 * A);
     float **rowsA[] = {&d.mu, &d.ls, &d.ok, &d.epsv, &d.anew, &d.a2};
@@ -169,9 +169,9 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     // ---- the launch sequence ----
     std::vector<gen::GemmJob> jobs;
     GenStage cur;
-    auto begin = [&]() {
+    auto begin = [&](int mode) {
         cur = GenStage{};
-        cur.kind = GS_GEMM; cur.base = jobs.size();
+        cur.kind = GS_GEMM; cur.mode = mode; cur.base = jobs.size();
         for (int q = 0; q < gen::GMAXJ; ++q) cur.gs.tile0[q] = 1 << 30;
     };
     auto add = [&](gen::GemmJob J) {
@@ -186,19 +186,26 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
     auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
 
-    plain(GS_PREP);
-    for (int l = 0; l < Lp; ++l) {                       // policy trunk on [s ; s']
+    const SlotLayout &XL = t->ext_layout;               // (the buffer's slots have the same layout: make_slot_layout(batch, O, A))
+    for (int l = 0; l < Lp; ++l) {                       // policy trunk on [s ; s']: the first layer reads the slot's rows
         const GenLayer &L = g->net[0].L[l];
-        begin(); add(gen_fwd(l == 0 ? d.XP : PH[l - 1], 2 * n, Wp(0, l), Bp(0, l), L.N, L.K, PH[l], 1)); end();
+        begin(0);
+        if (l == 0) {
+            gen::GemmJob Js = gen_fwd(nullptr, n, Wp(0, 0), Bp(0, 0), L.N, L.K, PH[0], 1), Jn = Js;
+            Js.a_slot = Jn.a_slot = 1; Js.a_off = XL.off_obs; Jn.a_off = XL.off_nobs; Jn.C = PH[0] + (long long)n * L.N;
+            add(Js); add(Jn);
+        } else {
+            add(gen_fwd(PH[l - 1], 2 * n, Wp(0, l), Bp(0, l), L.N, L.K, PH[l], 1));
+        }
+        end();
     }
     {
         const GenLayer &L = g->net[0].L[Lp];
-        begin(); add(gen_fwd(PH[Lp - 1], 2 * n, Wp(0, Lp), Bp(0, Lp), L.N, L.K, HD, 0)); end();
+        begin(0); add(gen_fwd(PH[Lp - 1], 2 * n, Wp(0, Lp), Bp(0, Lp), L.N, L.K, HD, 0)); end();
     }
     plain(GS_HEAD);
-    plain(GS_ALPHA);
     for (int l = 0; l <= Lq; ++l) {                      // Q1, Q2 on [(s,a) ; (s,a_new)], targets on (s',a')
-        begin();
+        begin(0);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[l];
             float *out = l < Lq ? QH[k][l] : QO[k];
@@ -213,14 +220,14 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     }
     plain(GS_LOSS);
     for (int j = Lq; j >= 1; --j) {                      // backward through layer j of Q1, Q2 (critic and actor rows)
-        begin();
+        begin(1);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[j];
             add(gen_bwd(j == Lq ? d.DQ[k] : dQZ[k][j], 2 * n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
         }
         end();
     }
-    begin();                                             // the actor rows' gradient w.r.t. the action columns of the input
+    begin(1);                                             // the actor rows' gradient w.r.t. the action columns of the input
     for (int k = 0; k < 2; ++k) {
         const GenLayer &L = g->net[1 + k].L[0];
         add(gen_bwd(dQZ[k][0] + (long long)n * L.N, n, L.N, Wp(1 + k, 0), L.K, O, A, DA[k], A, nullptr, 0));
@@ -229,12 +236,14 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     plain(GS_POLGRAD);
     for (int j = Lp; j >= 1; --j) {                      // backward through the policy (rows of s only)
         const GenLayer &L = g->net[0].L[j];
-        begin(); add(gen_bwd(j == Lp ? d.DHD : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PH[j - 1], L.K)); end();
+        begin(1); add(gen_bwd(j == Lp ? d.DHD : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PH[j - 1], L.K)); end();
     }
-    begin();                                             // every weight gradient of the step
+    begin(2);                                             // every weight gradient of the step
     for (int l = Lp; l >= 0; --l) {
         const GenLayer &L = g->net[0].L[l];
-        add(gen_dw(l == Lp ? d.DHD : dPZ[l], l == 0 ? d.XP : PH[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB));
+        gen::GemmJob Jw = gen_dw(l == Lp ? d.DHD : dPZ[l], l == 0 ? nullptr : PH[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB);
+        if (l == 0) { Jw.b_slot = 1; Jw.b_off = XL.off_obs; }
+        add(Jw);
     }
     for (int k = 0; k < 2; ++k)
         for (int l = Lq; l >= 0; --l) {
@@ -244,7 +253,6 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         }
     end();
     plain(GS_ADAM);
-    plain(GS_DIAG);
     SAC_REQUIRE(jobs.size() <= (size_t)16 * gen::GMAXJ, "internal: %zu matrix-product jobs", jobs.size());
     SAC_HIP(hipMemcpyAsync(g->d_jobs, jobs.data(), sizeof(gen::GemmJob) * jobs.size(), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
@@ -288,16 +296,26 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j)
     d.eps1 = t->dev.eps1; d.eps2 = t->dev.eps2;
     const int n = g->n, A = g->A;
     auto blocks = [](long long work, int cap) { const long long b = (work + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); };
+    SAC_REQUIRE(SL.off_obs == t->ext_layout.off_obs && SL.off_nobs == t->ext_layout.off_nobs && SL.Bt == n,
+                "internal: minibatch slot layout differs from the one the general step was built for");
     for (const GenStage &st : g->stages) {
         switch (st.kind) {
-        case GS_GEMM: hipLaunchKernelGGL(gen::k_g_gemm, dim3(st.gs.ntiles), dim3(256), 0, s, st.gs); break;
-        case GS_PREP: hipLaunchKernelGGL(gen::k_g_prep, dim3(blocks((long long)n * (2 * g->O + A), 2048)), dim3(256), 0, s, d, S, SL); break;
-        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, dim3(blocks(2LL * n, 1 << 20)), dim3(256), 0, s, d, sa); break;
-        case GS_ALPHA: hipLaunchKernelGGL(gen::k_g_alpha, dim3(1), dim3(256), 0, s, d, sa); break;
+        case GS_GEMM: {
+            gen::GemmStage gs = st.gs;
+            gs.S = S;
+            if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), dim3(gs.ntiles), dim3(256), 0, s, gs);
+            else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
+            else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
+            break;
+        }
+        case GS_HEAD: {         // (its rows need 2n threads; the copy of the slot's rows into the Q nets' input spreads over up to 128 workgroups)
+            const unsigned need = blocks(2LL * n, 1 << 20), copy = blocks((long long)n * (2 * g->O + A) / 4, 128);
+            hipLaunchKernelGGL(gen::k_g_head, dim3(need > copy ? need : copy), dim3(256), 0, s, d, S, SL, sa);
+            break;
+        }
         case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
         case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
-        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(blocks(g->adam_total, 2048)), dim3(256), 0, s, d, g->adam, sa); break;
-        case GS_DIAG: hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa); break;
+        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(1 + blocks(g->adam_total, 2048)), dim3(256), 0, s, d, g->adam, sa); break;
         }
     }
     SAC_HIP(hipGetLastError());

@@ -130,3 +130,26 @@ def test_acting_through_a_general_trainer():
     back = pickle.loads(pickle.dumps(pol))
     assert [w.shape for w, _ in back.layers.values()] == [(128, O), (96, 128), (80, 96), (A, 80), (A, 80)]
     assert np.allclose(back.get_actions(obs, deterministic=True), got, rtol=1e-5, atol=1e-6)
+
+
+def test_a_variant_with_other_hidden_sizes_runs_through_the_epoch_driver(tmp_path):
+    """--policy_hidden_sizes / --qf_hidden_sizes end up in variant['policy_kwargs'|'qf_kwargs'] (scripts/train.py:55-60):
+    the epoch driver runs such a variant unchanged, fused loop and stepwise interface log the same rows, and a checkpoint
+    written by the run restores into a trainer of the same shape."""
+    import json
+    from robosuite_benchmark_amd import variant
+    from robosuite_benchmark_amd.driver import experiment
+    v = variant.default_variant(env="Door", batch_size=64)
+    v["replay_buffer_size"] = 20_000
+    v["policy_kwargs"]["hidden_sizes"] = [512]
+    v["qf_kwargs"]["hidden_sizes"] = [300, 200, 100]
+    v["algorithm_kwargs"].update(num_trains_per_train_loop=30, min_num_steps_before_training=600,
+                                 num_expl_steps_per_train_loop=500, num_eval_steps_per_epoch=500)
+    a = experiment(json.loads(json.dumps(v)), log_dir=str(tmp_path), seed=3, num_epochs=2, quiet=True, fused_loop=True)
+    b = experiment(json.loads(json.dumps(v)), seed=3, num_epochs=2, quiet=True, fused_loop=False)
+    assert len(a) == 2 and np.isfinite(a[1]["trainer/QF1 Loss"])
+    for ra, rb in zip(a, b):
+        for k in ra:
+            if k.startswith("trainer/") or k.startswith("replay_buffer/"):
+                assert ra[k] == rb[k], k
+    assert (tmp_path / "progress.csv").exists()

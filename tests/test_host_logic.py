@@ -142,3 +142,27 @@ def test_rank_to_task_assignment():
     assert tasks == ["Lift", "Door", "Stack", "Wipe", "PickPlaceCan", "NutAssemblyRound", "TwoArmPegInHole",
                      "TwoArmHandoff"]
     assert parallel.aggregate_steps_per_second(8, 1000, 0.5) == 16000
+
+
+def test_hidden_sizes_any_depth_are_accepted_by_the_sac_holder_and_bounded():
+    """variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'] (arguments.py:98,104): SACTrainer takes 1..7 hidden layers of
+    1..4096 units (two of <= 256: the fused kernels, anything else: the general step); TD3 keeps the fused kernels' shapes."""
+    import pytest
+    from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy, TanhMlpPolicy, TD3Trainer
+
+    def sac(hp, hq):
+        pol = TanhGaussianPolicy(hp, 10, 3, rs=np.random.RandomState(0))
+        qs = [FlattenMlp(hq, 1, 13, rs=np.random.RandomState(1)) for _ in range(4)]
+        return SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3])     # (no handle yet: CPU)
+
+    t = sac([512, 512, 64], [300])
+    assert t._hidden("policy") == [512, 512, 64] and t._hidden("qf1") == [300]
+    assert t.policy.flat().size == 512 * 10 + 512 + 512 * 512 + 512 + 64 * 512 + 64 + 2 * (3 * 64 + 3)
+    for bad in ([], [64] * 8, [5000]):
+        with pytest.raises(RuntimeError, match="hidden_sizes"):
+            sac(bad, [256, 256])._hidden("policy")
+    pols = [TanhMlpPolicy([256, 256, 256], 3, 10, rs=np.random.RandomState(2)) for _ in range(2)]
+    qs = [FlattenMlp([256, 256], 1, 13, rs=np.random.RandomState(3)) for _ in range(4)]
+    td3 = TD3Trainer(policy=pols[0], qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], target_policy=pols[1])
+    with pytest.raises(RuntimeError, match="unsupported for TD3"):
+        td3._hidden("policy")
