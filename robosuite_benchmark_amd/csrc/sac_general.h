@@ -41,6 +41,7 @@ struct GemmJob {
 struct GemmStage {                  // kernel argument: the jobs of one launch (device array) + their first tiles
     const GemmJob *jobs;
     const float *S;                 // the step's minibatch slot
+    int stamp, pad_;                // (diagnostic build, -DSAC_STAMPS: this launch records its in-kernel timeline)
     int njobs, ntiles;
     int tile0[GMAXJ];
 };
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     const int tile = (int)blockIdx.x - J.tile0;
     const int m0 = GT * (tile / J.tiles_n), n0 = GT * (tile % J.tiles_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int Neff = J.N + (J.ones_col ? 1 : 0);
     constexpr bool a_rc = A_RC, b_rc = B_RC;
     // This thread's 16 elements of a chunk: fast coordinate `lane`, slow coordinates wave + 4 j (the row for an operand that is
     // contiguous along the reduction, else the reduction index).  Loads are UNCONDITIONAL from clamped indices -- a row or
@@ -115,32 +115,35 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     // being multiplied also waited for the next chunk's loads.  Offsets are 32-bit (checked at creation).
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int sa_m = (int)J.sa_m, sa_r = (int)J.sa_r, sb_n = (int)J.sb_n, sb_r = (int)J.sb_r;
-    int xoa[16], xob[16];                      // rc: the 16 rows' offsets; else [0]: this thread's row offset
+    // (rows clamped once; a FULL chunk is then 32 loads at uniform base + constant 32-bit lane offset -- the per-chunk address
+    //  arithmetic was 0.4 us of a 1.7 us chunk when every load computed its own 64-bit address: in-kernel stamps)
+    unsigned xoa[16], xob[16], offa[16], offb[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int ra = min(m0 + (a_rc ? wv + 4 * j : lane), J.M - 1), rb = min(n0 + (b_rc ? wv + 4 * j : lane), J.N - 1);
-        xoa[j] = ra * sa_m; xob[j] = rb * sb_n;
+        xoa[j] = (unsigned)(ra * sa_m); xob[j] = (unsigned)(rb * sb_n);
+        offa[j] = xoa[j] + (unsigned)((a_rc ? lane : wv + 4 * j) * sa_r);
+        offb[j] = xob[j] + (unsigned)((b_rc ? lane : wv + 4 * j) * sb_r);
     }
     const bool has_ones = J.ones_col && n0 <= J.N && J.N < n0 + GT;
     float xa[16], xb[16];
     auto fetch = [&](int s) {
         const int r0 = GK * s;
-        if constexpr (a_rc) {
-            const int ro = min(r0 + lane, J.R - 1) * sa_r;
+        if (r0 + GK <= J.R) {
+            const float *ca = Ap + (long long)r0 * J.sa_r, *cb = Bp + (long long)r0 * J.sb_r;       // uniform
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xa[j] = ld1g(Ap + (xoa[j] + ro));
-        } else {
+            for (int j = 0; j < 16; ++j) xa[j] = ld1g(ca + offa[j]);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xa[j] = ld1g(Ap + (xoa[0] + min(r0 + wv + 4 * j, J.R - 1) * sa_r));
+            for (int j = 0; j < 16; ++j) xb[j] = ld1g(cb + offb[j]);
+            return;
         }
-        if constexpr (b_rc) {
-            const int ro = min(r0 + lane, J.R - 1) * sb_r;
+        // the edge chunk: reduction indices clamped (their products are zeroed by fixup)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = ld1g(Bp + (xob[j] + ro));
-        } else {
+        for (int j = 0; j < 16; ++j)
+            xa[j] = ld1g(Ap + (xoa[a_rc ? j : 0] + (unsigned)(min(r0 + (a_rc ? lane : wv + 4 * j), J.R - 1) * sa_r)));
 #pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = ld1g(Bp + (xob[0] + min(r0 + wv + 4 * j, J.R - 1) * sb_r));
-        }
+        for (int j = 0; j < 16; ++j)
+            xb[j] = ld1g(Bp + (xob[b_rc ? j : 0] + (unsigned)(min(r0 + (b_rc ? lane : wv + 4 * j), J.R - 1) * sb_r)));
     };
     // behind the loads' arrival (in front of the LDS writes): the column of ones, the reduction's zero padding
     auto fixup = [&](int s) {
@@ -157,16 +160,26 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
             }
         }
     };
+#ifdef SAC_STAMPS
+#define GSTAMP(i) do { if (T.stamp) STAMP(0, i); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
     f32x4 acc[4] = {};
     const int nS = (J.R + GK - 1) / GK;
+    GSTAMP(0);
     fetch(0);
+    GSTAMP(1);
     for (int s = 0; s < nS; ++s) {
         if (s) __syncthreads();
+        if (s == 1) GSTAMP(2);
         fixup(s);
 #pragma unroll
         for (int j = 0; j < 16; ++j) { As[(wave + 4 * j) * GLD + lane] = xa[j]; Bs[(wave + 4 * j) * GLD + lane] = xb[j]; }
         __syncthreads();
+        if (s == 1) GSTAMP(3);
         if (s + 1 < nS) fetch(s + 1);
+        if (s == 1) GSTAMP(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 a, b[4];
@@ -189,25 +202,51 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
         }
+        if (s == 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); GSTAMP(5); }
     }
+    GSTAMP(6);
+    // epilogue: every load up front (clamped, unconditional, pinned in front of the arithmetic), stores through global
+    // pointers at 32-bit offsets, one predicate per element -- written with early-outs and conditional loads it compiled to
+    // a branch and a full wait per element: 2.2 us of a forward launch, 4.7 us of a masked one (in-kernel stamps)
+    float bv[4], mk[4][4];
+    const unsigned ldc = (unsigned)J.ldc, ldm = (unsigned)J.ldmask;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned nc = (unsigned)min(n0 + 16 * t + c, J.N - 1);
+        bv[t] = ld1g((J.bias ? J.bias : Bp) + (J.bias ? nc : 0u));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mc = (unsigned)min(m0 + 16 * wave + 4 * g + i, J.M - 1);
+            mk[t][i] = ld1g((J.mask ? J.mask : Bp) + (J.mask ? mc * ldm + nc : 0u));
+        }
+    }
+    SB();
+    const bool has_bias = J.bias != nullptr, has_mask = J.mask != nullptr;
+    float *const Cg = J.C;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int n = n0 + 16 * t + c;
-        if (n >= Neff) continue;
-        const bool ones = J.ones_col && n == J.N;
-        const float bv = (J.bias && !ones) ? J.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + 16 * wave + 4 * g + i;
-            if (m >= J.M) continue;
-            float v = acc[t][i];
-            if (ones) { J.c_ones[m] = v; continue; }
-            v += bv;
+            float v = acc[t][i] + (has_bias ? bv[t] : 0.f);
             if (J.relu) v = fmaxf(v, 0.f);
-            if (J.mask) v = (J.mask[(long long)m * J.ldmask + n] > 0.f) ? v : 0.f;
-            J.C[(long long)m * J.ldc + n] = v;
+            if (has_mask) v = (mk[t][i] > 0.f) ? v : 0.f;
+            if (m < J.M && n < J.N) *(__attribute__((address_space(1))) float *)(uintptr_t)(Cg + ((unsigned)m * ldc + (unsigned)n)) = v;
         }
     }
+    if (has_ones) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (n0 + 16 * t + c == J.N) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + 16 * wave + 4 * g + i;
+                    if (m < J.M) *(__attribute__((address_space(1))) float *)(uintptr_t)(J.c_ones + m) = acc[t][i];
+                }
+            }
+    }
+    GSTAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------

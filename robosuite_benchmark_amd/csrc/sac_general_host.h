@@ -303,6 +303,9 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j)
         case GS_GEMM: {
             gen::GemmStage gs = st.gs;
             gs.S = S;
+#ifdef SAC_STAMPS
+            { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - g->stages.data())) ? 1 : 0; }
+#endif
             if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), dim3(gs.ntiles), dim3(256), 0, s, gs);
             else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
             else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
