@@ -26,6 +26,7 @@ constexpr int GMAXL = 8;            // layers of one network: up to 7 hidden lay
 constexpr int GMAXJ = 24;           // jobs of one launch (the weight-gradient launch: 3 networks x GMAXL)
 constexpr int GT = 64;              // output tile (rows and columns)
 constexpr int GLD = GT + 4;         // LDS row stride of a staged operand chunk
+constexpr int GK = 64;              // reduction chunk
 
 struct GemmJob {
     const float *A;                 // A(m, r) = A[m sa_m + r sa_r]
@@ -36,12 +37,20 @@ struct GemmJob {
     long long sa_m, sa_r, sb_n, sb_r, ldc, ldmask;
     long long a_off, b_off;         // a_slot / b_slot: the operand lives in the step's minibatch slot, at this offset (floats)
     int M, N, R;
-    int relu, ones_col, tiles_n, tile0, a_slot, b_slot, pad_;
+    int relu, ones_col, tiles_n, tile0, a_slot, b_slot;
+    int a_vec, b_vec, pad_;         // the operand may be fetched in 16-byte pieces (alignment and extents checked by the host)
 };
 struct GemmStage {                  // kernel argument: the jobs of one launch (device array) + their first tiles
     const GemmJob *jobs;
     const float *S;                 // the step's minibatch slot
-    int stamp, pad_;                // (diagnostic build, -DSAC_STAMPS: this launch records its in-kernel timeline)
+    int stamp;                      // (diagnostic build, -DSAC_STAMPS: this launch records its in-kernel timeline)
+    // split reduction (launches with few tiles: a 256-row batch leaves most of the chip idle): `splitk` workgroups share a
+    // tile, each takes a contiguous range of the reduction's chunks and leaves its partial tile in `scratch`; the LAST one
+    // to finish adds the partials in the fixed order 0 .. splitk-1 (deterministic whatever the arrival order) and runs the
+    // epilogue.  tile_cnt: one arrival counter per tile, back at 0 when the launch ends.
+    int splitk;
+    float *scratch;
+    unsigned *tile_cnt;
     int njobs, ntiles;
     int tile0[GMAXJ];
 };
@@ -83,16 +92,109 @@ struct AdamArgs {
 // contiguous along the reduction, [r][row] otherwise: conflict-free writes either way -- and the next chunk's loads are in
 // flight while this one's 64 MFMAs per wave run.  The MFMA with index i of k-group (q, g) contracts r = 16 q + 4 g + i for
 // both operands, so an operand stored [row][r] is read with one 16-byte LDS load per four MFMAs.
+// One operand's share of a chunk in one thread: 16 values v[k] at chunk coordinates (slow, fast) -- for an operand that is
+// contiguous along the reduction (RC) that is (row, r), else (r, row); the chunk sits in LDS as [slow][fast].
+//   scalar map: slow = wave + 4 k, fast = lane               (16 dword loads, a wave reads 256 contiguous bytes)
+//   vector map: slow = (tid >> 4) + 16 (k >> 2), fast = 4 (tid & 15) + (k & 3)
+//               (4 loads of 16 bytes, 4 LDS writes of 16 bytes: when base, row stride and extent along `fast` allow it)
+// Loads are UNCONDITIONAL from clamped indices -- a row beyond the matrix repeats the last one (its products land in
+// outputs that are never stored), the reduction's padding is zeroed in the edge chunk only -- and go through explicitly
+// GLOBAL pointers.  Both matter: a conditional load is a branch whose merge point waits for the data, and a generic
+// pointer (these come out of a table read with scalar loads) makes a flat load, which counts on lgkmcnt too, so that
+// every wait for an LDS read of the chunk being multiplied also waited for the next chunk's loads.  A FULL chunk is
+// loaded at uniform base + constant 32-bit lane offsets (offsets are 32-bit: checked at creation).
+template <bool RC>
+struct GOperand {
+    const float *P;
+    int sx, sr, X, R, x0, ones_x;     // strides (floats), rows, reduction length, the tile's first row, local row of ones (-1: none)
+    bool vec;
+    unsigned off[16];
+    float v[16];
+    __device__ __forceinline__ int slow_of(int k) const {
+        const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        return vec ? (tid >> 4) + 16 * (k >> 2) : wv + 4 * k;
+    }
+    __device__ __forceinline__ int fast_of(int k) const {
+        const int tid = threadIdx.x;
+        return vec ? 4 * (tid & 15) + (k & 3) : (tid & 63);
+    }
+    __device__ __forceinline__ unsigned addr(int row_l, int r) const {       // clamped element offset
+        return (unsigned)(min(x0 + row_l, X - 1) * sx + min(r, R - 1) * sr);
+    }
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) off[k] = RC ? addr(slow_of(k), fast_of(k)) : addr(fast_of(k), slow_of(k));
+        // (vector map, k = 4 j: the 16 bytes at off[4 j]; an operand that is contiguous along its rows clamps whole vectors)
+        if (vec && !RC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[4 * j] = (unsigned)(min(x0 + fast_of(4 * j), X - 4) * sx + min(slow_of(4 * j), R - 1) * sr);
+        }
+    }
+    __device__ __forceinline__ void fetch(int s) {
+        const int r0 = GK * s;
+        if (r0 + GK <= R) {
+            const float *cb = P + (long long)r0 * sr;                       // uniform
+            if (vec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 q = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(cb + off[4 * j]);
+                    v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = ld1g(cb + off[k]);
+            }
+            return;
+        }
+        // the edge chunk: reduction indices clamped (their products are zeroed by fix); whole vectors stay inside R (R % 4 == 0)
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned o = RC ? (unsigned)(min(x0 + slow_of(4 * j), X - 1) * sx + min(r0 + fast_of(4 * j), R - 4) * sr)
+                                      : (unsigned)(min(x0 + fast_of(4 * j), X - 4) * sx + min(r0 + slow_of(4 * j), R - 1) * sr);
+                const f32x4 q = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(P + o);
+                v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = ld1g(P + (RC ? addr(slow_of(k), r0 + fast_of(k)) : addr(fast_of(k), r0 + slow_of(k))));
+        }
+    }
+    // behind the loads' arrival, in front of the LDS writes: the row of ones, the reduction's zero padding.  (A vector that
+    // was clamped back into the matrix holds OTHER elements than its coordinates say: rows beyond X only, whose products
+    // are never stored -- except the row of ones, which is set here by coordinate.)
+    __device__ __forceinline__ void fix(int s) {
+        const int r0 = GK * s;
+        if (ones_x >= 0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if ((RC ? slow_of(k) : fast_of(k)) == ones_x) v[k] = 1.0f;
+        }
+        if (r0 + GK > R) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (r0 + (RC ? fast_of(k) : slow_of(k)) >= R) v[k] = 0.f;
+        }
+    }
+    __device__ __forceinline__ void write(float *lds) const {
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) st4(lds + slow_of(4 * j) * GLD + fast_of(4 * j), f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]});
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lds[slow_of(k) * GLD + fast_of(k)] = v[k];
+        }
+    }
+};
+
 // A_RC / B_RC (compile time: the jobs of a launch share them): the operand is contiguous along the reduction -- forward
 // (true, true), backward through a layer (true, false), weight gradient (false, false).  Only the thread -> element map
 // and the LDS layout depend on it; the addresses always use the job's strides.
-constexpr int GK = 64;
 template <bool A_RC, bool B_RC>
 __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     __shared__ __attribute__((aligned(16))) float As[GT * GLD], Bs[GT * GLD];
+    const int splitk = T.splitk, tile_lin = (int)blockIdx.x / splitk, ks = (int)blockIdx.x - tile_lin * splitk;
     int li = 0;
 #pragma unroll
-    for (int q = 1; q < GMAXJ; ++q) li = ((int)blockIdx.x >= T.tile0[q]) ? q : li;
+    for (int q = 1; q < GMAXJ; ++q) li = (tile_lin >= T.tile0[q]) ? q : li;
     union { GemmJob J; unsigned long long w[sizeof(GemmJob) / 8]; } ud;
     {
         const __attribute__((address_space(4))) unsigned long long *src =
@@ -102,83 +204,36 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     }
     const GemmJob &J = ud.J;
     const float *const Ap = J.a_slot ? T.S + J.a_off : J.A, *const Bp = J.b_slot ? T.S + J.b_off : J.Bm;
-    const int tile = (int)blockIdx.x - J.tile0;
+    const int tile = tile_lin - J.tile0;
     const int m0 = GT * (tile / J.tiles_n), n0 = GT * (tile % J.tiles_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
     constexpr bool a_rc = A_RC, b_rc = B_RC;
-    // This thread's 16 elements of a chunk: fast coordinate `lane`, slow coordinates wave + 4 j (the row for an operand that is
-    // contiguous along the reduction, else the reduction index).  Loads are UNCONDITIONAL from clamped indices -- a row or
-    // column beyond the matrix repeats the last one (its products land in outputs that are never stored), the reduction's
-    // padding is zeroed in the last chunk only -- and go through explicitly GLOBAL pointers.  Both matter: a conditional
-    // load is a branch whose merge point waits for the data, and a generic pointer (these come out of a table read with
-    // scalar loads) makes a flat load, which counts on lgkmcnt too, so that every wait for an LDS read of the chunk
-    // being multiplied also waited for the next chunk's loads.  Offsets are 32-bit (checked at creation).
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int sa_m = (int)J.sa_m, sa_r = (int)J.sa_r, sb_n = (int)J.sb_n, sb_r = (int)J.sb_r;
-    // (rows clamped once; a FULL chunk is then 32 loads at uniform base + constant 32-bit lane offset -- the per-chunk address
-    //  arithmetic was 0.4 us of a 1.7 us chunk when every load computed its own 64-bit address: in-kernel stamps)
-    unsigned xoa[16], xob[16], offa[16], offb[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int ra = min(m0 + (a_rc ? wv + 4 * j : lane), J.M - 1), rb = min(n0 + (b_rc ? wv + 4 * j : lane), J.N - 1);
-        xoa[j] = (unsigned)(ra * sa_m); xob[j] = (unsigned)(rb * sb_n);
-        offa[j] = xoa[j] + (unsigned)((a_rc ? lane : wv + 4 * j) * sa_r);
-        offb[j] = xob[j] + (unsigned)((b_rc ? lane : wv + 4 * j) * sb_r);
-    }
-    const bool has_ones = J.ones_col && n0 <= J.N && J.N < n0 + GT;
-    float xa[16], xb[16];
-    auto fetch = [&](int s) {
-        const int r0 = GK * s;
-        if (r0 + GK <= J.R) {
-            const float *ca = Ap + (long long)r0 * J.sa_r, *cb = Bp + (long long)r0 * J.sb_r;       // uniform
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xa[j] = ld1g(ca + offa[j]);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) xb[j] = ld1g(cb + offb[j]);
-            return;
-        }
-        // the edge chunk: reduction indices clamped (their products are zeroed by fixup)
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            xa[j] = ld1g(Ap + (xoa[a_rc ? j : 0] + (unsigned)(min(r0 + (a_rc ? lane : wv + 4 * j), J.R - 1) * sa_r)));
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            xb[j] = ld1g(Bp + (xob[b_rc ? j : 0] + (unsigned)(min(r0 + (b_rc ? lane : wv + 4 * j), J.R - 1) * sb_r)));
-    };
-    // behind the loads' arrival (in front of the LDS writes): the column of ones, the reduction's zero padding
-    auto fixup = [&](int s) {
-        const int r0 = GK * s;
-        if (has_ones) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) if (n0 + (b_rc ? wv + 4 * j : lane) == J.N) xb[j] = 1.0f;
-        }
-        if (r0 + GK > J.R) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (r0 + (a_rc ? lane : wv + 4 * j) >= J.R) xa[j] = 0.f;
-                if (r0 + (b_rc ? lane : wv + 4 * j) >= J.R) xb[j] = 0.f;
-            }
-        }
-    };
+    GOperand<a_rc> oa;
+    GOperand<b_rc> ob;
+    oa.P = Ap; oa.sx = (int)J.sa_m; oa.sr = (int)J.sa_r; oa.X = J.M; oa.R = J.R; oa.x0 = m0; oa.ones_x = -1; oa.vec = J.a_vec != 0;
+    ob.P = Bp; ob.sx = (int)J.sb_n; ob.sr = (int)J.sb_r; ob.X = J.N; ob.R = J.R; ob.x0 = n0; ob.vec = J.b_vec != 0;
+    ob.ones_x = (J.ones_col && n0 <= J.N && J.N < n0 + GT) ? J.N - n0 : -1;
+    const bool has_ones = ob.ones_x >= 0;
+    oa.init(); ob.init();
 #ifdef SAC_STAMPS
 #define GSTAMP(i) do { if (T.stamp) STAMP(0, i); } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
     f32x4 acc[4] = {};
-    const int nS = (J.R + GK - 1) / GK;
+    const int nSall = (J.R + GK - 1) / GK;
+    const int sfirst = (ks * nSall) / splitk, nS = ((ks + 1) * nSall) / splitk;       // this workgroup's chunks [sfirst, nS)
     GSTAMP(0);
-    fetch(0);
+    oa.fetch(sfirst); ob.fetch(sfirst);
     GSTAMP(1);
-    for (int s = 0; s < nS; ++s) {
-        if (s) __syncthreads();
+    for (int s = sfirst; s < nS; ++s) {
+        if (s > sfirst) __syncthreads();
         if (s == 1) GSTAMP(2);
-        fixup(s);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { As[(wave + 4 * j) * GLD + lane] = xa[j]; Bs[(wave + 4 * j) * GLD + lane] = xb[j]; }
+        oa.fix(s); ob.fix(s);
+        oa.write(As); ob.write(Bs);
         __syncthreads();
         if (s == 1) GSTAMP(3);
-        if (s + 1 < nS) fetch(s + 1);
+        if (s + 1 < nS) { oa.fetch(s + 1); ob.fetch(s + 1); }
         if (s == 1) GSTAMP(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -205,6 +260,41 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
         if (s == 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); GSTAMP(5); }
     }
     GSTAMP(6);
+    if (splitk > 1) {
+        __shared__ unsigned am_last;
+        float *mine = T.scratch + ((size_t)tile_lin * splitk + ks) * (GT * GT);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st4_sc1(mine + (t * 256 + tid) * 4, acc[t]);
+        // (the hand-off protocol of the fused step, sac_fused.h: write-through stores, every wave waits for its own, a
+        //  workgroup barrier, ONE relaxed agent-scope increment -- a __threadfence() / an acq_rel atomic here writes the
+        //  whole L2 back and invalidates it: 27 us per launch, measured)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(T.tile_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            am_last = (old == (unsigned)splitk - 1u) ? 1u : 0u;
+            if (am_last) __hip_atomic_store(T.tile_cnt + tile_lin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!am_last) return;
+        // (all partials requested at once -- fetched one dependent load at a time this tail took 28 us -- then added in order.
+        //  Plain loads are coherent here: the partials were written through (sc1) and fenced before their counter
+        //  increment, and this workgroup touches these lines for the first time in a launch that began with invalidated
+        //  caches)
+        const float *all = T.scratch + (size_t)tile_lin * splitk * (GT * GT);
+        f32x4 part[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                part[k][t] = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(all + (size_t)(k < splitk ? k : 0) * (GT * GT) + (t * 256 + tid) * 4);
+        SB();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc[t] = part[0][t];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (k < splitk) acc[t] += part[k][t];
+        }
+    }
     // epilogue: every load up front (clamped, unconditional, pinned in front of the arithmetic), stores through global
     // pointers at 32-bit offsets, one predicate per element -- written with early-outs and conditional loads it compiled to
     // a branch and a full wait per element: 2.2 us of a forward launch, 4.7 us of a masked one (in-kernel stamps)
@@ -307,10 +397,9 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
     // ---- the last workgroup: mean(log_pi) -> the entropy coefficient ----
     __shared__ float red[256];
     __shared__ unsigned am_last;
-    __threadfence();
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (log pi left through sc1 stores: see k_g_gemm's split tail)
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(d.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(d.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         am_last = (old == gridDim.x - 1) ? 1u : 0u;
         if (am_last) __hip_atomic_store(d.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next step
     }

@@ -6,7 +6,7 @@ struct GenLayer { int N = 0, K = 0; long long offW = 0, offB = 0; };
 struct GenNet {
     int nl = 0;
     GenLayer L[gen::GMAXL];
-    long long n = 0;
+    long long n = 0, nflat = 0;             // floats of the device vector (every W starts on a 16-byte boundary) / of the flat vector
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     std::vector<long long> perm;            // flat (sac_get_params) index -> index in the device vector
 };
@@ -21,6 +21,7 @@ struct sac_general {
     gen::AdamArgs adam{};
     char *arena = nullptr;
     gen::GemmJob *d_jobs = nullptr;
+    float *d_scratch = nullptr; unsigned *d_tile_cnt = nullptr;      // split reductions (sac_general.h: GemmStage::splitk)
     std::vector<GenStage> stages;
     long long adam_total = 0;
 };
@@ -37,29 +38,35 @@ struct GenBump {
 };
 
 void gen_shape_net(GenNet &N, const int *hidden, int nh, int in_dim, int out_dim, bool merged_heads, int A) {
-    long long off = 0;
+    long long off = 0, flat = 0;
     int d = in_dim;
     N.nl = nh + 1;
     for (int l = 0; l <= nh; ++l) {
         GenLayer &L = N.L[l];
         L.N = (l < nh) ? hidden[l] : out_dim; L.K = d;
+        off = (off + 3) & ~3LL;                              // (16-byte loads of the matrix-product kernel)
         L.offW = off; off += (long long)L.N * L.K;
         L.offB = off; off += L.N;
+        flat += (long long)L.N * L.K + L.N;
         d = L.N;
     }
-    N.n = off;
-    // flat layout: per layer W then b; the policy's two heads are two layers there (last_fc, last_fc_log_std) and ONE
-    // layer of 2A outputs here ([W_mean ; W_log_std] then [b_mean ; b_log_std])
-    N.perm.resize((size_t)off);
-    for (long long i = 0; i < off; ++i) N.perm[(size_t)i] = i;
-    if (merged_heads) {
-        const GenLayer &Hd = N.L[nh];
-        const long long h0 = Hd.offW, AK = (long long)A * Hd.K;
-        long long fi = h0;
-        for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = h0 + i;                   // last_fc.weight
-        for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = Hd.offB + a;                     // last_fc.bias
-        for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = h0 + AK + i;              // last_fc_log_std.weight
-        for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = Hd.offB + A + a;                 // last_fc_log_std.bias
+    N.n = (off + 3) & ~3LL; N.nflat = flat;
+    // flat layout: per layer W then b, packed; the policy's two heads are two layers there (last_fc, last_fc_log_std) and
+    // ONE layer of 2A outputs here ([W_mean ; W_log_std] then [b_mean ; b_log_std])
+    N.perm.resize((size_t)flat);
+    long long fi = 0;
+    for (int l = 0; l <= nh; ++l) {
+        const GenLayer &L = N.L[l];
+        if (l == nh && merged_heads) {
+            const long long AK = (long long)A * L.K;
+            for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = L.offW + i;               // last_fc.weight
+            for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = L.offB + a;                      // last_fc.bias
+            for (long long i = 0; i < AK; ++i) N.perm[(size_t)fi++] = L.offW + AK + i;          // last_fc_log_std.weight
+            for (int a = 0; a < A; ++a) N.perm[(size_t)fi++] = L.offB + A + a;                  // last_fc_log_std.bias
+        } else {
+            for (long long i = 0; i < (long long)L.N * L.K; ++i) N.perm[(size_t)fi++] = L.offW + i;
+            for (int i = 0; i < L.N; ++i) N.perm[(size_t)fi++] = L.offB + i;
+        }
     }
 }
 
@@ -174,14 +181,38 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         cur.kind = GS_GEMM; cur.mode = mode; cur.base = jobs.size();
         for (int q = 0; q < gen::GMAXJ; ++q) cur.gs.tile0[q] = 1 << 30;
     };
+    // may an operand be fetched in 16-byte pieces?  rc (contiguous along the reduction): base, row stride and R multiples of
+    // four floats; else (contiguous along its rows): base, reduction stride and the row count
+    auto vec_ok = [](const float *p, long long slot_off, bool in_slot, long long s_row, long long s_red, int rows, int R, bool rc) {
+        const bool aligned = in_slot ? (slot_off % 4 == 0) : ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+        if (getenv("SAC_GEN_NO_VEC")) return 0;              // (A/B comparisons)
+        return (int)(rc ? (aligned && s_red == 1 && s_row % 4 == 0 && R % 4 == 0 && R >= 4)
+                        : (aligned && s_row == 1 && s_red % 4 == 0 && rows % 4 == 0 && rows >= 4));
+    };
     auto add = [&](gen::GemmJob J) {
+        J.a_vec = vec_ok(J.A, J.a_off, J.a_slot != 0, J.sa_m, J.sa_r, J.M, J.R, cur.mode != 2);
+        J.b_vec = vec_ok(J.Bm, J.b_off, J.b_slot != 0, J.sb_n, J.sb_r, J.N, J.R, cur.mode == 0);
         J.tiles_n = (J.N + (J.ones_col ? 1 : 0) + gen::GT - 1) / gen::GT;
         J.tile0 = cur.gs.ntiles;
         cur.gs.tile0[cur.gs.njobs++] = J.tile0;
         cur.gs.ntiles += ((J.M + gen::GT - 1) / gen::GT) * J.tiles_n;
         jobs.push_back(J);
     };
-    auto end = [&]() { g->stages.push_back(cur); };
+    long long scratch_floats = 0;
+    int max_tiles = 0;
+    auto end = [&]() {
+        // few tiles and a long reduction: split the reduction over up to four workgroups per tile (never the weight-gradient
+        // launch: many tiles, four chunks)
+        int min_chunks = 1 << 30;
+        for (size_t i = cur.base; i < jobs.size(); ++i) min_chunks = std::min(min_chunks, (jobs[i].R + gen::GK - 1) / gen::GK);
+        int sk = 1;
+        if (cur.mode != 2 && !getenv("SAC_GEN_NO_SPLITK"))
+            while (sk < 4 && 2 * sk <= min_chunks && cur.gs.ntiles * 2 * sk <= 256) sk *= 2;
+        cur.gs.splitk = sk;
+        if (sk > 1) scratch_floats = std::max(scratch_floats, (long long)cur.gs.ntiles * sk * gen::GT * gen::GT);
+        max_tiles = std::max(max_tiles, cur.gs.ntiles);
+        g->stages.push_back(cur);
+    };
     auto plain = [&](int kind) { GenStage s; s.kind = kind; g->stages.push_back(s); };
     auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
     auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
@@ -256,7 +287,12 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     SAC_REQUIRE(jobs.size() <= (size_t)16 * gen::GMAXJ, "internal: %zu matrix-product jobs", jobs.size());
     SAC_HIP(hipMemcpyAsync(g->d_jobs, jobs.data(), sizeof(gen::GemmJob) * jobs.size(), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    for (auto &s : g->stages) if (s.kind == GS_GEMM) s.gs.jobs = g->d_jobs + s.base;
+    if (scratch_floats) SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_scratch), sizeof(float) * (size_t)scratch_floats));
+    SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_tile_cnt), sizeof(unsigned) * (size_t)(max_tiles + 1)));
+    SAC_HIP(hipMemsetAsync(g->d_tile_cnt, 0, sizeof(unsigned) * (size_t)(max_tiles + 1), t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    for (auto &s : g->stages)
+        if (s.kind == GS_GEMM) { s.gs.jobs = g->d_jobs + s.base; s.gs.scratch = g->d_scratch; s.gs.tile_cnt = g->d_tile_cnt; }
     // debug views (sac_debug_fetch)
     return 0;
 }
@@ -264,13 +300,15 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
 void gen_destroy(sac_general *g) {
     if (!g) return;
     if (g->arena) (void)hipFree(g->arena);
+    if (g->d_scratch) (void)hipFree(g->d_scratch);
+    if (g->d_tile_cnt) (void)hipFree(g->d_tile_cnt);
     delete g;
 }
 
 int gen_upload(sac_trainer *t, int net, const float *flat, float *dst) {
     const GenNet &N = t->gen->net[net];
-    std::vector<float> h((size_t)N.n);
-    for (long long i = 0; i < N.n; ++i) h[(size_t)N.perm[(size_t)i]] = flat[i];
+    std::vector<float> h((size_t)N.n, 0.f);
+    for (long long i = 0; i < N.nflat; ++i) h[(size_t)N.perm[(size_t)i]] = flat[i];
     SAC_HIP(hipMemcpyAsync(dst, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
     return 0;
@@ -281,7 +319,7 @@ int gen_download(sac_trainer *t, int net, const float *src, float *flat) {
     std::vector<float> h((size_t)N.n);
     SAC_HIP(hipMemcpyAsync(h.data(), src, sizeof(float) * h.size(), hipMemcpyDeviceToHost, t->stream));
     SAC_HIP(hipStreamSynchronize(t->stream));
-    for (long long i = 0; i < N.n; ++i) flat[i] = h[(size_t)N.perm[(size_t)i]];
+    for (long long i = 0; i < N.nflat; ++i) flat[i] = h[(size_t)N.perm[(size_t)i]];
     return 0;
 }
 
@@ -306,9 +344,10 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j)
 #ifdef SAC_STAMPS
             { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - g->stages.data())) ? 1 : 0; }
 #endif
-            if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), dim3(gs.ntiles), dim3(256), 0, s, gs);
-            else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
-            else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), dim3(gs.ntiles), dim3(256), 0, s, gs);
+            const dim3 grid(gs.ntiles * gs.splitk);
+            if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), grid, dim3(256), 0, s, gs);
+            else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), grid, dim3(256), 0, s, gs);
+            else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), grid, dim3(256), 0, s, gs);
             break;
         }
         case GS_HEAD: {         // (its rows need 2n threads; the copy of the slot's rows into the Q nets' input spreads over up to 128 workgroups)
@@ -348,9 +387,9 @@ int64_t gen_debug_fetch(sac_trainer *t, const std::string &nm, float *out, int64
     const char *gn[3] = {"g_policy", "g_qf1", "g_qf2"};
     for (int i = 0; i < 3; ++i)
         if (nm == gn[i]) {
-            if (cap < g->net[i].n) { sac::set_error("buffer too small"); return -2; }
+            if (cap < g->net[i].nflat) { sac::set_error("buffer too small"); return -2; }
             if (gen_download(t, i, g->net[i].G, out)) return -1;
-            return g->net[i].n;
+            return g->net[i].nflat;
         }
     sac::set_error("unknown debug tensor '%s'", nm.c_str());
     return -2;

@@ -27,6 +27,7 @@
 // unconditional loads, global stores behind the last load request, compile-time variants inside GEMM loops.
 #include "sac_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -2478,7 +2479,7 @@ int sac_trainer_destroy(sac_trainer_t *t) {
 
 int64_t sac_param_count(const sac_trainer_t *t, int net) {
     if (!t || net < 0 || net > (t->algo == 1 ? 5 : 4)) return -1;
-    if (t->gen) return t->gen->net[net].n;
+    if (t->gen) return t->gen->net[net].nflat;
     return flat_count(flat_map(t, net));
 }
 

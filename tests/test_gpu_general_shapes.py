@@ -153,3 +153,23 @@ def test_a_variant_with_other_hidden_sizes_runs_through_the_epoch_driver(tmp_pat
             if k.startswith("trainer/") or k.startswith("replay_buffer/"):
                 assert ra[k] == rb[k], k
     assert (tmp_path / "progress.csv").exists()
+
+
+@pytest.mark.parametrize("kw,B", [(dict(use_automatic_entropy_tuning=False, reward_scale=2.0, discount=0.9), 80),
+                                  (dict(target_update_period=1, soft_target_tau=0.05, policy_lr=3e-4, qf_lr=3e-4), 1024),
+                                  (dict(target_entropy=-3.0, target_update_period=2), 17)])
+def test_trainer_kwargs_reach_the_general_step(kw, B):
+    """trainer_kwargs (scripts/train.py:29-37) other than the defaults -- fixed alpha, reward scale, discount, Polyak period /
+    tau, learning rates, target entropy -- and batch sizes on both sides of the tile size, three steps against the oracle."""
+    O, A = TASK_DIMS["Door"]
+    oracle, hip = make_pair(O, A, B, seed=5, hidden=(384, 192), hidden_q=(448, 320), **kw)
+    assert hip.fused_mode() == 3
+    for s_ in range(3):
+        np_batch, eps = batch_and_noise(B, O, A, seed=900 + s_, term_frac=0.1)
+        want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"], np_batch["terminals"],
+                           np_batch["next_observations"], *eps)
+        check_diag(hip.train(np_batch, eps=eps), want, tol=1e-4 if s_ else TOL)
+    st, after = hip.state_dict(), oracle.export_nets()
+    for name in ("target_qf1", "target_qf2"):           # Polyak: applied on the steps the period says, with the tau given
+        assert rel_err(st["params"][name], flat_of(after[name])) < 2e-5, name
+    assert abs(st["scalars"][5] - float(oracle.log_alpha.exp().detach() if oracle.auto_alpha else 1.0)) < 1e-6
