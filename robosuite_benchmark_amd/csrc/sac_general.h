@@ -350,9 +350,9 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
 __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     {
-        const long long tot = (long long)n * (2 * O + A);
-        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long long)gridDim.x * 256) {
-            const int b = (int)(e / (2 * O + A)), k = (int)(e % (2 * O + A));
+        const int w = 2 * O + A, tot = n * w;               // (32-bit: checked at creation)
+        for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < tot; e += (int)(gridDim.x * 256)) {
+            const int b = e / w, k = e - b * w;
             if (k < O) {
                 const float v = S[SL.off_obs + (long long)b * O + k];
                 d.XQ[(long long)b * ldq + k] = v;
@@ -364,13 +364,14 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
             }
         }
     }
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    // thread = (row, action): 16 lanes per row (A <= 16), the row's log-prob by a 16-lane butterfly
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
     if (r < 2 * n) {
         const int side = r >= n ? 1 : 0, b = r - side * n;
         const float *epp = side ? d.eps2 : d.eps1;
         const float *hd = d.HD + (long long)r * 2 * A;
-        float lsum = 0.f;
-        for (int a = 0; a < A; ++a) {
+        float lp = 0.f;
+        if (a < A) {
             const float mean = hd[a], raw = hd[A + a];
             const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
             const float stdv = expf(lstd);
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
             const float dd = __fsub_rn(zz, mean);                               // Normal.log_prob(z) - log(1 - a^2 + eps)
             const float var = __fmul_rn(stdv, stdv);
             const float nlp = -(dd * dd) / (2.0f * var) - logf(stdv) - 0.91893853320467274178f;
-            lsum += nlp - logf(1.0f - act * act + TANH_EPS);
+            lp = nlp - logf(1.0f - act * act + TANH_EPS);
             const long long gi = (long long)b * A + a;
             if (!side) {
                 d.mu[gi] = mean; d.ls[gi] = lstd; d.ok[gi] = (raw >= LOG_SIG_MIN && raw <= LOG_SIG_MAX) ? 1.0f : 0.0f;
@@ -392,7 +393,8 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
                 d.XQ[(long long)(2 * n + b) * ldq + O + a] = act;
             }
         }
-        st_sc1((side ? d.logpi2 : d.logpi) + b, lsum);
+        const float lsum = group16_sum(lp);
+        if (a == 0) st_sc1((side ? d.logpi2 : d.logpi) + b, lsum);
     }
     // ---- the last workgroup: mean(log_pi) -> the entropy coefficient ----
     __shared__ float red[256];
@@ -468,7 +470,10 @@ __device__ void diag_block(const GDev &d, const StepArg &sa);
 // torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets; workgroup 0
 // computes the step's diagnostics instead (it reads nothing this launch writes)
 __global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) {
-    if (blockIdx.x == 0) { diag_block(d, sa); return; }
+    if (blockIdx.x == 0) {          // (the diagnostics of the steps somebody reads: the first and the last of a loop, single steps)
+        if ((sa.pad2 & 2u) || sa.loop_pos == 0) diag_block(d, sa);
+        return;
+    }
     const bool polyak = (sa.step_now % d.period) == 0;
     const float bc2s = (float)sa.bc2s;
     const long long tot = P.n[0] + P.n[1] + P.n[2];

@@ -207,7 +207,7 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         for (size_t i = cur.base; i < jobs.size(); ++i) min_chunks = std::min(min_chunks, (jobs[i].R + gen::GK - 1) / gen::GK);
         int sk = 1;
         if (cur.mode != 2 && !getenv("SAC_GEN_NO_SPLITK"))
-            while (sk < 4 && 2 * sk <= min_chunks && cur.gs.ntiles * 2 * sk <= 256) sk *= 2;
+            while (sk < 4 && 2 * sk <= min_chunks && cur.gs.ntiles * 2 * sk <= 512) sk *= 2;      // (up to two workgroups per CU)
         cur.gs.splitk = sk;
         if (sk > 1) scratch_floats = std::max(scratch_floats, (long long)cur.gs.ntiles * sk * gen::GT * gen::GT);
         max_tiles = std::max(max_tiles, cur.gs.ntiles);
@@ -351,7 +351,7 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j)
             break;
         }
         case GS_HEAD: {         // (its rows need 2n threads; the copy of the slot's rows into the Q nets' input spreads over up to 128 workgroups)
-            const unsigned need = blocks(2LL * n, 1 << 20), copy = blocks((long long)n * (2 * g->O + A) / 4, 128);
+            const unsigned need = (unsigned)((2 * n + 15) / 16), copy = blocks((long long)n * (2 * g->O + A) / 4, 128);
             hipLaunchKernelGGL(gen::k_g_head, dim3(need > copy ? need : copy), dim3(256), 0, s, d, S, SL, sa);
             break;
         }
