@@ -667,6 +667,32 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
         out["ingest"] = dict(rows=2500, call_returns_us=round((t1 - t0) * 1e6, 1), landed_us=round((t2 - t0) * 1e6, 1),
                              note="sac_buffer_add_f64 of one epoch's exploration steps: pack into pinned staging + enqueue "
                                   "(call returns) vs rows resident in HBM")
+    if world == 1 and not args.no_stepwise:
+        # hidden_sizes the fused kernels do not carry (arguments.py:98,104): the library's general step on
+        # the same buffer -- an extra data point, never `value`
+        from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy
+        gs = {}
+        for hs in ([512, 512], [256, 256, 256]):
+            rs = np.random.RandomState(3)
+            pol = TanhGaussianPolicy(hs, O, A, rs=rs, b_init_value=B_INIT)
+            qs = [FlattenMlp(hs, 1, O + A, rs=rs, b_init_value=B_INIT) for _ in range(4)]
+            tg = SACTrainer(policy=pol, qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], policy_lr=1e-3, qf_lr=5e-4,
+                            soft_target_tau=0.005, target_update_period=5, batch_size=B, noise_seed=3, device=device)
+            tg.train_loop(buf, 50, batch_size=B)
+            n_g = min(args.steps, 500)
+            t0 = time.perf_counter()
+            _, last_g = tg.train_loop(buf, n_g, batch_size=B)
+            dt = time.perf_counter() - t0
+            # multiply-adds x 2 of one step: policy forward on s and s' + backward + dW (8 B Pp); each Q net forward and
+            # backward on (s,a) and (s,a_new) + dW (10 B Pq); each target forward (2 B Pq)
+            gflop = B * (8.0 * pol.flat().size + 24.0 * qs[0].flat().size) * 1e-9
+            gs["x".join(map(str, hs))] = dict(value=round(n_g / dt, 1), unit="grad-steps/s", us_per_step=round(1e6 * dt / n_g, 2),
+                                               step_kind=tg.fused_mode(), finite=bool(np.all(np.isfinite(last_g))),
+                                               gflop_per_step=round(gflop, 3), tflops=round(gflop * n_g / dt * 1e-3, 2))
+            del tg
+        out["general_step"] = dict(shapes=gs, note="hidden_sizes beyond two layers of <= 256 units: one launch per layer and pass "
+                                                   "direction (csrc/sac_general.h); steps include the index draw and the gather")
+        buf.seed(17)
     if world == 1 and args.replicas_per_gpu > 1:
         out["concurrent_replicas"] = concurrent_replicas(task, O, A, B, args.replicas_per_gpu, args.steps, device,
                                                          by_xcd=args.xcd_replicas, fused=args.fused_replicas, split=args.split_replicas)
