@@ -1,12 +1,13 @@
 """Diagnostic: in-kernel wall-clock stamps of the fused step k_abc (needs the -DSAC_STAMPS build:
-scratch/libsac_hip_stamps_<tag>.so).   usage: python scratch/stamps_fused.py <tag> [batch]"""
+scratch/libsac_hip_stamps_<tag>.so).   usage: python scratch/stamps_fused.py <tag> [batch [obs_dim act_dim]]"""
 import ctypes as C, sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robosuite_benchmark_amd import _lib
 _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsac_hip_stamps_%s.so" % sys.argv[1])
 import bench
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-tr, buf = bench.build_replica("Lift", 42, 7, B, 100_000, 17, 0)
+O, A = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (42, 7)
+tr, buf = bench.build_replica("X", O, A, B, 100_000, 17, 0)
 tr.train_loop(buf, 200, batch_size=B)
 lib = _lib.load()
 out = np.zeros(5 * 512 * 16, np.uint64)
@@ -65,3 +66,4 @@ for st_i, nm in ((1, "A done"), (6, "B done"), (9, "end")):
             if ((b & 7) ^ XOR) < 4:
                 g[f(b)].append((w[b, st_i] - t0) / 100.0)
         print(f"critic chain {nm:7s} by {key:5s}:", " ".join(f"{k}:{np.median(v):.2f}" for k, v in sorted(g.items())))
+
