@@ -189,6 +189,9 @@ typedef struct td3_config {
     int32_t qf_hidden[2];
 } td3_config_t;
 int td3_trainer_create(sac_trainer_t **out, const td3_config_t *cfg);
+/* as sac_trainer_create_mlp: hidden_sizes of any depth / width for TD3 (two layers of at most 256 units: the fused kernels) */
+int td3_trainer_create_mlp(sac_trainer_t **out, const td3_config_t *cfg, const int32_t *policy_hidden, int32_t n_policy_hidden,
+                           const int32_t *qf_hidden, int32_t n_qf_hidden);
 
 /* diagnostics vector written per step; names = the 'trainer/...' columns of progress.csv
  * (/root/reference/runs/.../progress.csv:1) plus the optimised actor loss. */
@@ -213,7 +216,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg);
  * runs the GENERAL step: the same step in the same order as a sequence of 2 Lp + 2 Lq + 11 launches around one
  * matrix-product kernel (csrc/sac_general.h), results within fp32 round-off of the oracle like the fused kernels'
  * (tests/test_gpu_general_shapes.py); sac_trainer_step_kind reports 3.  Every sac_* entry point works on such a handle except
- * sac_profile_loop.  SAC only (TD3 handles keep the two layers of at most 256 units). */
+ * sac_profile_loop.  (TD3: td3_trainer_create_mlp.) */
 int sac_trainer_create_mlp(sac_trainer_t **out, const sac_config_t *cfg, const int32_t *policy_hidden, int32_t n_policy_hidden,
                            const int32_t *qf_hidden, int32_t n_qf_hidden);
 int sac_trainer_destroy(sac_trainer_t *t);

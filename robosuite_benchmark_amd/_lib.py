@@ -84,6 +84,7 @@ SYMBOLS = {
     "sac_trainer_create": (C.c_int, [C.POINTER(_P), C.POINTER(SacConfig)]),
     "sac_trainer_create_mlp": (C.c_int, [C.POINTER(_P), C.POINTER(SacConfig), _P, C.c_int32, _P, C.c_int32]),
     "td3_trainer_create": (C.c_int, [C.POINTER(_P), C.POINTER(Td3Config)]),
+    "td3_trainer_create_mlp": (C.c_int, [C.POINTER(_P), C.POINTER(Td3Config), _P, C.c_int32, _P, C.c_int32]),
     "sac_trainer_destroy": (C.c_int, [_P]),
     "sac_param_count": (C.c_int64, [_P, C.c_int]),
     "sac_set_params": (C.c_int, [_P, C.c_int, _P, C.c_int64]),

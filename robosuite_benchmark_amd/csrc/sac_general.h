@@ -74,6 +74,15 @@ struct GDev {
     float *DHD;                     // head gradient [n][2A]
     float *diag_first, *diag_last, *diag_trace, *diag_dev;
     const float *eps1, *eps2;
+    // TD3 (algo 1; rlkit TD3Trainer): XQ holds [(s, a) ; (s', a~)]; QO = {Q1, Q2 on (s, a), target Q1, Q2 on (s', a~)} [n] each
+    int algo;
+    float td3_sigma, td3_clip;
+    const float *HDT, *HDP;         // head pre-activations [n][A]: target policy on s' / online policy on s
+    float *XA, *pa;                 // the actor pass: Q1's input rows [obs | tanh(mean)] [n][O + A]; the policy action [n][A]
+    const float *QA;                // Q1(s, pi(s)) [n]
+    float *DQA;                     // its loss gradient (-1/n) [n]
+    const float *DAa;               // dL/da through Q1 [n][A]
+    float *DHP;                     // head gradient [n][A]
 };
 
 struct AdamArgs {
@@ -466,12 +475,14 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
 }
 
 __device__ void diag_block(const GDev &d, const StepArg &sa);
+__device__ void td3_diag_block(const GDev &d, const StepArg &sa);
 
 // torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets; workgroup 0
 // computes the step's diagnostics instead (it reads nothing this launch writes)
 __global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) {
-    if (blockIdx.x == 0) {          // (the diagnostics of the steps somebody reads: the first and the last of a loop, single steps)
-        if ((sa.pad2 & 2u) || sa.loop_pos == 0) diag_block(d, sa);
+    if (blockIdx.x == 0) {          // (SAC: the diagnostics of the steps somebody reads -- the first and the last of a loop, single steps)
+        if (d.algo == 1) td3_diag_block(d, sa);
+        else if ((sa.pad2 & 2u) || sa.loop_pos == 0) diag_block(d, sa);
         return;
     }
     const bool polyak = (sa.step_now % d.period) == 0;
@@ -551,6 +562,135 @@ __device__ void diag_block(const GDev &d, const StepArg &sa) {
         dlast[i] = out[i];
         if (sa.loop_pos == 0) d.diag_first[i] = out[i];
         if (sa.loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)sa.loop_pos * SAC_DIAG_N + i] = out[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TD3 (rlkit TD3Trainer, /root/reference/util/rlkit_utils.py:107-135) on the same launches: a critic pass every step, an
+// actor pass on policy steps (and, without updates, on the steps whose statistics somebody reads)
+// ------------------------------------------------------------------------------------------
+// critic pass: the Q nets' input rows [(s, a) ; (s', a~)], a~ = tanh(target policy(s')) + clamp(N(0,1) sigma, +-clip)
+// (the sum is NOT clipped to the action range)
+__global__ __launch_bounds__(256) void k_g_td3_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
+    const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    {
+        const int w = 2 * O + A, tot = n * w;
+        for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < tot; e += (int)(gridDim.x * 256)) {
+            const int b = e / w, k = e - b * w;
+            if (k < O) d.XQ[(long long)b * ldq + k] = S[SL.off_obs + (long long)b * O + k];
+            else if (k < 2 * O) d.XQ[(long long)(n + b) * ldq + (k - O)] = S[SL.off_nobs + (long long)b * O + (k - O)];
+            else d.XQ[(long long)b * ldq + O + (k - 2 * O)] = S[SL.off_act + (long long)b * A + (k - 2 * O)];
+        }
+    }
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
+    if (b < n && a < A) {
+        const float eps = d.eps2 ? d.eps2[(long long)b * A + a]
+                                 : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(b * d.NI + a), 1u);
+        const float act = tanhf(d.HDT[(long long)b * A + a]) + fminf(fmaxf(eps * d.td3_sigma, -d.td3_clip), d.td3_clip);
+        d.a2[(long long)b * A + a] = act;
+        d.XQ[(long long)(n + b) * ldq + O + a] = act;
+    }
+}
+
+// y = reward_scale r + (1 - d) discount min(T1, T2)(s', a~); dL/dq_i = 2 (q_i - y) / n
+__global__ __launch_bounds__(256) void k_g_td3_loss(GDev d, const float *__restrict__ S, SlotLayout SL) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= d.n) return;
+    const float invB = 1.0f / (float)d.n;
+    const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, fminf(d.QO[2][b], d.QO[3][b]));
+    d.y[b] = y;
+    d.DQ[0][b] = 2.0f * (d.QO[0][b] - y) * invB;
+    d.DQ[1][b] = 2.0f * (d.QO[1][b] - y) * invB;
+}
+
+// actor pass: Q1's input rows [obs | tanh(policy(s))]; the loss -mean Q1 has the gradient -1/n on every row
+__global__ __launch_bounds__(256) void k_g_td3_ahead(GDev d, const float *__restrict__ S, SlotLayout SL) {
+    const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < n * O; e += (int)(gridDim.x * 256)) {
+        const int b = e / O, k = e - b * O;
+        d.XA[(long long)b * ldq + k] = S[SL.off_obs + (long long)b * O + k];
+    }
+    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
+    if (b < n && a < A) {
+        const float act = tanhf(d.HDP[(long long)b * A + a]);
+        d.pa[(long long)b * A + a] = act;
+        d.XA[(long long)b * ldq + O + a] = act;
+        if (a == 0) d.DQA[b] = -1.0f / (float)n;
+    }
+}
+
+// dL/d(pre-tanh) = dL/da (1 - a^2)
+__global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)d.n * d.A) return;
+    const float act = d.pa[e];
+    d.DHP[e] = d.DAa[e] * (1.0f - act * act);
+}
+
+// TD3's statistics in the slots of the SAC vector (sac_hip.h): sa.pad bit 0 = the critic part (every step), bit 1 = the policy
+// part (policy / statistics steps).  The device copy keeps the most recent value of every entry; a launch whose caller
+// reads the diagnostics copies the whole vector out at its end.
+__device__ void td3_diag_block(const GDev &d, const StepArg &sa) {
+    constexpr int NS = 6;        // q1, q2, y, be1, be2, policy action
+    const int n = d.n, A = d.A, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, loop_pos = sa.loop_pos;
+    double sm[NS], sq[NS], lsum = 0;
+    float mx[NS], mn[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) { sm[q] = 0; sq[q] = 0; mx[q] = -INFINITY; mn[q] = INFINITY; }
+    auto acc1 = [&](int q, float v) { sm[q] += v; sq[q] += (double)v * v; mx[q] = fmaxf(mx[q], v); mn[q] = fminf(mn[q], v); };
+    if (sa.pad & 1)
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float yv = d.y[i], q1 = d.QO[0][i], q2 = d.QO[1][i];
+            acc1(0, q1); acc1(1, q2); acc1(2, yv); acc1(3, (q1 - yv) * (q1 - yv)); acc1(4, (q2 - yv) * (q2 - yv));
+        }
+    if (sa.pad & 2) {
+        for (int i = threadIdx.x; i < n; i += 256) lsum += (double)d.QA[i];
+        for (int e = threadIdx.x; e < n * A; e += 256) acc1(5, d.pa[e]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            sm[q] += __shfl_xor(sm[q], o); sq[q] += __shfl_xor(sq[q], o);
+            mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o)); mn[q] = fminf(mn[q], __shfl_xor(mn[q], o));
+        }
+        lsum += __shfl_xor(lsum, o);
+    }
+    __shared__ double sh[4][32];
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) { sh[wave][q] = sm[q]; sh[wave][6 + q] = sq[q]; sh[wave][12 + q] = mx[q]; sh[wave][18 + q] = mn[q]; }
+        sh[wave][24] = lsum;
+    }
+    __syncthreads();
+    float *const dlast = d.diag_dev;
+    auto put = [&](int di, float v) {
+        dlast[di] = v;
+        if (loop_pos == 0) d.diag_first[di] = v;
+        if (loop_pos < DIAG_TRACE_CAP) d.diag_trace[(size_t)loop_pos * SAC_DIAG_N + di] = v;
+    };
+    if (threadIdx.x < NS) {
+        const int q = threadIdx.x;
+        if ((q < 5) ? (sa.pad & 1) : (sa.pad & 2)) {
+            double s = 0, s2 = 0, MX = -INFINITY, MN = INFINITY;
+            for (int w = 0; w < 4; ++w) { s += sh[w][q]; s2 += sh[w][6 + q]; MX = fmax(MX, sh[w][12 + q]); MN = fmin(MN, sh[w][18 + q]); }
+            const double cnt = (q < 5) ? (double)n : (double)n * A;
+            const double mean = s / cnt;
+            double var = s2 / cnt - mean * mean;
+            if (var < 0) var = 0;
+            const int base = (q < 3) ? SAC_D_Q1_MEAN + 4 * q : SAC_D_LOGPI_MEAN + 4 * (q - 3);
+            put(base, (float)mean); put(base + 1, (float)sqrt(var)); put(base + 2, (float)MX); put(base + 3, (float)MN);
+            if (q == 3) put(SAC_D_QF1_LOSS, (float)mean);           // MSE = mean Bellman error
+            if (q == 4) put(SAC_D_QF2_LOSS, (float)mean);
+        }
+    } else if (threadIdx.x == 64 && (sa.pad & 2)) {
+        double s = 0;
+        for (int w = 0; w < 4; ++w) s += sh[w][24];
+        put(SAC_D_POLICY_LOSS, (float)(-s / n));
+    }
+    if (sa.pad2 & 2u) {
+        __syncthreads();
+        if (threadIdx.x < SAC_DIAG_N) d.diag_last[threadIdx.x] = ld_sc1(d.diag_dev + threadIdx.x);
     }
 }
 

@@ -10,15 +10,20 @@ struct GenNet {
     float *P = nullptr, *M = nullptr, *V = nullptr, *G = nullptr;
     std::vector<long long> perm;            // flat (sac_get_params) index -> index in the device vector
 };
+constexpr int GEN_MAX_JOBS = 16 * gen::GMAXJ;
 struct GenStage { int kind = 0, mode = 0; size_t base = 0; gen::GemmStage gs{}; };   // mode: 0 forward, 1 backward, 2 weight gradients   // kind 0: a k_g_gemm launch; else see launch
-enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_ADAM };
+enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_ADAM, GS_TD3_HEAD, GS_TD3_LOSS, GS_TD3_AHEAD, GS_TD3_POLGRAD };
 
 struct sac_general {
     int n = 0, O = 0, A = 0, Lp = 0, Lq = 0;
     int hp[gen::GMAXL] = {}, hq[gen::GMAXL] = {};
-    GenNet net[5];
+    GenNet net[6];                                    // 5: TD3's target policy
     gen::GDev dev{};
     gen::AdamArgs adam{};
+    // TD3: the critic pass (every step), the actor pass (policy steps), the actor pass's forward half (statistics steps);
+    // Adam on the critics without / with the Polyak targets, on the policy (+ target policy), on nothing (statistics only)
+    std::vector<GenStage> td3_critic, td3_actor, td3_stats;
+    gen::AdamArgs adam_q{}, adam_q_tp{}, adam_pi{}, adam_none{};
     char *arena = nullptr;
     gen::GemmJob *d_jobs = nullptr;
     float *d_scratch = nullptr; unsigned *d_tile_cnt = nullptr;      // split reductions (sac_general.h: GemmStage::splitk)
@@ -101,6 +106,67 @@ gen::GemmJob gen_dw(const float *dY, const float *X, int rows, int Nl, int K, fl
     return J;
 }
 
+// builds the launch lists of a trainer: matrix-product launches as tables of jobs + the small kernels in between
+struct GenPlanner {
+    std::vector<gen::GemmJob> jobs;
+    std::vector<GenStage> *list = nullptr;
+    GenStage cur;
+    long long scratch_floats = 0;
+    int max_tiles = 0;
+    void begin(int mode) {
+        cur = GenStage{};
+        cur.kind = GS_GEMM; cur.mode = mode; cur.base = jobs.size();
+        for (int q = 0; q < gen::GMAXJ; ++q) cur.gs.tile0[q] = 1 << 30;
+    }
+    // may an operand be fetched in 16-byte pieces?  rc (contiguous along the reduction): base, row stride and R multiples of
+    // four floats; else (contiguous along its rows): base, reduction stride and the row count
+    static int vec_ok(const float *p, long long slot_off, bool in_slot, long long s_row, long long s_red, int rows, int R, bool rc) {
+        const bool aligned = in_slot ? (slot_off % 4 == 0) : ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+        if (getenv("SAC_GEN_NO_VEC")) return 0;              // (A/B comparisons)
+        return (int)(rc ? (aligned && s_red == 1 && s_row % 4 == 0 && R % 4 == 0 && R >= 4)
+                        : (aligned && s_row == 1 && s_red % 4 == 0 && rows % 4 == 0 && rows >= 4));
+    }
+    void add(gen::GemmJob J) {
+        J.a_vec = vec_ok(J.A, J.a_off, J.a_slot != 0, J.sa_m, J.sa_r, J.M, J.R, cur.mode != 2);
+        J.b_vec = vec_ok(J.Bm, J.b_off, J.b_slot != 0, J.sb_n, J.sb_r, J.N, J.R, cur.mode == 0);
+        J.tiles_n = (J.N + (J.ones_col ? 1 : 0) + gen::GT - 1) / gen::GT;
+        J.tile0 = cur.gs.ntiles;
+        cur.gs.tile0[cur.gs.njobs++] = J.tile0;
+        cur.gs.ntiles += ((J.M + gen::GT - 1) / gen::GT) * J.tiles_n;
+        jobs.push_back(J);
+    }
+    void end() {
+        // few tiles and a long reduction: split the reduction over up to four workgroups per tile (never the weight-gradient
+        // launch: many tiles, four chunks)
+        int min_chunks = 1 << 30;
+        for (size_t i = cur.base; i < jobs.size(); ++i) min_chunks = std::min(min_chunks, (jobs[i].R + gen::GK - 1) / gen::GK);
+        int sk = 1;
+        if (cur.mode != 2 && !getenv("SAC_GEN_NO_SPLITK"))
+            while (sk < 4 && 2 * sk <= min_chunks && cur.gs.ntiles * 2 * sk <= 512) sk *= 2;      // (up to two workgroups per CU)
+        cur.gs.splitk = sk;
+        if (sk > 1) scratch_floats = std::max(scratch_floats, (long long)cur.gs.ntiles * sk * gen::GT * gen::GT);
+        max_tiles = std::max(max_tiles, cur.gs.ntiles);
+        list->push_back(cur);
+    }
+    void one(int mode, const gen::GemmJob &J) { begin(mode); add(J); end(); }
+    void plain(int kind) { GenStage s; s.kind = kind; list->push_back(s); }
+};
+
+// the planner's jobs to the device, the split reductions' scratch, the lists' device pointers
+int gen_commit_plan(sac_trainer *t, GenPlanner &pl, std::initializer_list<std::vector<GenStage> *> lists) {
+    sac_general *g = t->gen;
+    SAC_REQUIRE(pl.jobs.size() <= (size_t)GEN_MAX_JOBS, "internal: %zu matrix-product jobs", pl.jobs.size());
+    SAC_HIP(hipMemcpyAsync(g->d_jobs, pl.jobs.data(), sizeof(gen::GemmJob) * pl.jobs.size(), hipMemcpyHostToDevice, t->stream));
+    if (pl.scratch_floats) SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_scratch), sizeof(float) * (size_t)pl.scratch_floats));
+    SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_tile_cnt), sizeof(unsigned) * (size_t)(pl.max_tiles + 1)));
+    SAC_HIP(hipMemsetAsync(g->d_tile_cnt, 0, sizeof(unsigned) * (size_t)(pl.max_tiles + 1), t->stream));
+    SAC_HIP(hipStreamSynchronize(t->stream));
+    for (auto *L : lists)
+        for (auto &s : *L)
+            if (s.kind == GS_GEMM) { s.gs.jobs = g->d_jobs + s.base; s.gs.scratch = g->d_scratch; s.gs.tile_cnt = g->d_tile_cnt; }
+    return 0;
+}
+
 int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     sac_general *g = new sac_general();
     t->gen = g;
@@ -146,7 +212,7 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     bump.want(&t->d_eps, 2LL * t->B * A);
     bump.want(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP));
     bump.want(&t->d_ctl, 1);
-    bump.want(&g->d_jobs, 16 * gen::GMAXJ);
+    bump.want(&g->d_jobs, GEN_MAX_JOBS);
     {
         const size_t bytes = (bump.total + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->arena), bytes));
@@ -174,46 +240,12 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     }
 
     // ---- the launch sequence ----
-    std::vector<gen::GemmJob> jobs;
-    GenStage cur;
-    auto begin = [&](int mode) {
-        cur = GenStage{};
-        cur.kind = GS_GEMM; cur.mode = mode; cur.base = jobs.size();
-        for (int q = 0; q < gen::GMAXJ; ++q) cur.gs.tile0[q] = 1 << 30;
-    };
-    // may an operand be fetched in 16-byte pieces?  rc (contiguous along the reduction): base, row stride and R multiples of
-    // four floats; else (contiguous along its rows): base, reduction stride and the row count
-    auto vec_ok = [](const float *p, long long slot_off, bool in_slot, long long s_row, long long s_red, int rows, int R, bool rc) {
-        const bool aligned = in_slot ? (slot_off % 4 == 0) : ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
-        if (getenv("SAC_GEN_NO_VEC")) return 0;              // (A/B comparisons)
-        return (int)(rc ? (aligned && s_red == 1 && s_row % 4 == 0 && R % 4 == 0 && R >= 4)
-                        : (aligned && s_row == 1 && s_red % 4 == 0 && rows % 4 == 0 && rows >= 4));
-    };
-    auto add = [&](gen::GemmJob J) {
-        J.a_vec = vec_ok(J.A, J.a_off, J.a_slot != 0, J.sa_m, J.sa_r, J.M, J.R, cur.mode != 2);
-        J.b_vec = vec_ok(J.Bm, J.b_off, J.b_slot != 0, J.sb_n, J.sb_r, J.N, J.R, cur.mode == 0);
-        J.tiles_n = (J.N + (J.ones_col ? 1 : 0) + gen::GT - 1) / gen::GT;
-        J.tile0 = cur.gs.ntiles;
-        cur.gs.tile0[cur.gs.njobs++] = J.tile0;
-        cur.gs.ntiles += ((J.M + gen::GT - 1) / gen::GT) * J.tiles_n;
-        jobs.push_back(J);
-    };
-    long long scratch_floats = 0;
-    int max_tiles = 0;
-    auto end = [&]() {
-        // few tiles and a long reduction: split the reduction over up to four workgroups per tile (never the weight-gradient
-        // launch: many tiles, four chunks)
-        int min_chunks = 1 << 30;
-        for (size_t i = cur.base; i < jobs.size(); ++i) min_chunks = std::min(min_chunks, (jobs[i].R + gen::GK - 1) / gen::GK);
-        int sk = 1;
-        if (cur.mode != 2 && !getenv("SAC_GEN_NO_SPLITK"))
-            while (sk < 4 && 2 * sk <= min_chunks && cur.gs.ntiles * 2 * sk <= 512) sk *= 2;      // (up to two workgroups per CU)
-        cur.gs.splitk = sk;
-        if (sk > 1) scratch_floats = std::max(scratch_floats, (long long)cur.gs.ntiles * sk * gen::GT * gen::GT);
-        max_tiles = std::max(max_tiles, cur.gs.ntiles);
-        g->stages.push_back(cur);
-    };
-    auto plain = [&](int kind) { GenStage s; s.kind = kind; g->stages.push_back(s); };
+    GenPlanner pl;
+    pl.list = &g->stages;
+    auto begin = [&](int mode) { pl.begin(mode); };
+    auto add = [&](const gen::GemmJob &J) { pl.add(J); };
+    auto end = [&]() { pl.end(); };
+    auto plain = [&](int kind) { pl.plain(kind); };
     auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
     auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
 
@@ -284,17 +316,164 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         }
     end();
     plain(GS_ADAM);
-    SAC_REQUIRE(jobs.size() <= (size_t)16 * gen::GMAXJ, "internal: %zu matrix-product jobs", jobs.size());
-    SAC_HIP(hipMemcpyAsync(g->d_jobs, jobs.data(), sizeof(gen::GemmJob) * jobs.size(), hipMemcpyHostToDevice, t->stream));
-    SAC_HIP(hipStreamSynchronize(t->stream));
-    if (scratch_floats) SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_scratch), sizeof(float) * (size_t)scratch_floats));
-    SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_tile_cnt), sizeof(unsigned) * (size_t)(max_tiles + 1)));
-    SAC_HIP(hipMemsetAsync(g->d_tile_cnt, 0, sizeof(unsigned) * (size_t)(max_tiles + 1), t->stream));
-    SAC_HIP(hipStreamSynchronize(t->stream));
-    for (auto &s : g->stages)
-        if (s.kind == GS_GEMM) { s.gs.jobs = g->d_jobs + s.base; s.gs.scratch = g->d_scratch; s.gs.tile_cnt = g->d_tile_cnt; }
-    // debug views (sac_debug_fetch)
-    return 0;
+    return gen_commit_plan(t, pl, {&g->stages});
+}
+
+// TD3 (td3_trainer_create_mlp): nets 0 policy (one head of A outputs, tanh), 1, 2 critics, 3, 4 their targets, 5 target policy
+int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_, const int *hq, int nq_) {
+    sac_general *g = new sac_general();
+    t->gen = g;
+    const int n = t->Bt, O = t->O, A = t->A;
+    g->n = n; g->O = O; g->A = A; g->Lp = np_; g->Lq = nq_;
+    for (int i = 0; i < np_; ++i) g->hp[i] = hp[i];
+    for (int i = 0; i < nq_; ++i) g->hq[i] = hq[i];
+    gen_shape_net(g->net[0], hp, np_, O, A, false, A);
+    gen_shape_net(g->net[5], hp, np_, O, A, false, A);
+    for (int i = 1; i < 5; ++i) gen_shape_net(g->net[i], hq, nq_, O + A, 1, false, A);
+    const int Lp = np_, Lq = nq_, ldq = O + A;
+    {
+        long long widest = ldq;
+        for (int i = 0; i < np_; ++i) widest = hp[i] > widest ? hp[i] : widest;
+        for (int i = 0; i < nq_; ++i) widest = hq[i] > widest ? hq[i] : widest;
+        SAC_REQUIRE(3LL * n * widest < (1LL << 31) && widest * widest < (1LL << 31),
+                    "batch %d x layer width %lld is beyond the general step's 32-bit operand offsets", n, widest);
+    }
+    GenBump bump;
+    for (int i = 0; i < 6; ++i) {
+        bump.want(&g->net[i].P, g->net[i].n);
+        if (i < 3) { bump.want(&g->net[i].M, g->net[i].n); bump.want(&g->net[i].V, g->net[i].n); bump.want(&g->net[i].G, g->net[i].n); }
+    }
+    gen::GDev &d = g->dev;
+    float *PHT[gen::GMAXL] = {}, *PHP[gen::GMAXL] = {}, *dPZ[gen::GMAXL] = {}, *HDT = nullptr, *HDP = nullptr;
+    float *QH[2][gen::GMAXL] = {}, *TH[2][gen::GMAXL] = {}, *dQZ[2][gen::GMAXL] = {}, *QO[4] = {};
+    float *AH[gen::GMAXL] = {}, *dAZ[gen::GMAXL] = {}, *QA = nullptr, *DAa = nullptr;
+    bump.want(&d.XQ, 2LL * n * ldq); bump.want(&d.XA, (long long)n * ldq); bump.want(&d.done, 64);
+    for (int l = 0; l < Lp; ++l) { bump.want(&PHT[l], (long long)n * hp[l]); bump.want(&PHP[l], (long long)n * hp[l]); bump.want(&dPZ[l], (long long)n * hp[l]); }
+    bump.want(&HDT, (long long)n * A); bump.want(&HDP, (long long)n * A);
+    bump.want(&d.a2, (long long)n * A); bump.want(&d.pa, (long long)n * A); bump.want(&d.DHP, (long long)n * A); bump.want(&DAa, (long long)n * A);
+    bump.want(&d.y, n); bump.want(&QA, n); bump.want(&d.DQA, n);
+    for (int k = 0; k < 2; ++k) {
+        for (int l = 0; l < Lq; ++l) { bump.want(&QH[k][l], (long long)n * hq[l]); bump.want(&TH[k][l], (long long)n * hq[l]); bump.want(&dQZ[k][l], (long long)n * hq[l]); }
+        bump.want(&QO[k], n); bump.want(&QO[2 + k], n); bump.want(&d.DQ[k], n);
+    }
+    for (int l = 0; l < Lq; ++l) { bump.want(&AH[l], (long long)n * hq[l]); bump.want(&dAZ[l], (long long)n * hq[l]); }
+    t->ext_layout = make_slot_layout(t->Bt, O, A);
+    bump.want(&t->ext_slot, t->ext_layout.slot_floats);
+    bump.want(&t->d_eps, 2LL * t->B * A);
+    bump.want(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP));
+    bump.want(&t->d_ctl, 1);
+    bump.want(&g->d_jobs, GEN_MAX_JOBS);
+    {
+        const size_t bytes = (bump.total + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->arena), bytes));
+        SAC_HIP(hipMemsetAsync(g->arena, 0, bytes, t->stream));
+        for (auto &r : bump.req) *r.first = g->arena + r.second;
+    }
+    d.n = n; d.O = O; d.A = A; d.NI = 16; d.ldq = ldq; d.algo = 1;
+    d.discount = c->discount; d.reward_scale = c->reward_scale; d.tau = c->tau; d.period = 1; d.auto_alpha = 0;
+    d.noise_seed = c->noise_seed; d.ctl = t->d_ctl;
+    d.td3_sigma = c->target_policy_noise; d.td3_clip = c->target_policy_noise_clip;
+    d.HDT = HDT; d.HDP = HDP; d.QA = QA; d.DAa = DAa;
+    for (int k = 0; k < 4; ++k) d.QO[k] = QO[k];
+    d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
+    d.diag_dev = t->d_diag;
+    d.eps1 = d.eps2 = nullptr;
+    auto adam_of = [&](gen::AdamArgs &ad, std::initializer_list<int> nets, bool with_targets, float lr) {
+        ad = gen::AdamArgs{};
+        int k = 0;
+        for (int i : nets) {
+            ad.P[k] = g->net[i].P; ad.M[k] = g->net[i].M; ad.V[k] = g->net[i].V; ad.G[k] = g->net[i].G;
+            ad.TP[k] = with_targets ? g->net[i == 0 ? 5 : i + 2].P : nullptr;
+            ad.n[k] = g->net[i].n; ad.lr[k] = lr;
+            ++k;
+        }
+    };
+    adam_of(g->adam_q, {1, 2}, false, c->qf_learning_rate);
+    adam_of(g->adam_q_tp, {1, 2}, true, c->qf_learning_rate);
+    adam_of(g->adam_pi, {0}, true, c->policy_learning_rate);
+    adam_of(g->adam_none, {}, false, 0.f);
+
+    GenPlanner pl;
+    const SlotLayout &XL = t->ext_layout;
+    auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
+    auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
+    // a policy (net) forward on the slot's rows at `off`: trunk into PHx, head pre-activations into HD
+    auto policy_fwd = [&](int net, long long off, float **PHx, float *HD) {
+        for (int l = 0; l <= Lp; ++l) {
+            const GenLayer &L = g->net[net].L[l];
+            gen::GemmJob J = gen_fwd(l == 0 ? nullptr : PHx[l - 1], n, Wp(net, l), Bp(net, l), L.N, L.K, l < Lp ? PHx[l] : HD, l < Lp);
+            if (l == 0) { J.a_slot = 1; J.a_off = off; }
+            pl.one(0, J);
+        }
+    };
+    // ---- the critic pass ----
+    pl.list = &g->td3_critic;
+    policy_fwd(5, XL.off_nobs, PHT, HDT);
+    pl.plain(GS_TD3_HEAD);
+    for (int l = 0; l <= Lq; ++l) {                      // Q1, Q2 on (s, a), their targets on (s', a~)
+        pl.begin(0);
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[1 + k].L[l];
+            pl.add(gen_fwd(l == 0 ? d.XQ : QH[k][l - 1], n, Wp(1 + k, l), Bp(1 + k, l), L.N, L.K, l < Lq ? QH[k][l] : QO[k], l < Lq));
+        }
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[3 + k].L[l];
+            pl.add(gen_fwd(l == 0 ? d.XQ + (long long)n * ldq : TH[k][l - 1], n, Wp(3 + k, l), Bp(3 + k, l), L.N, L.K, l < Lq ? TH[k][l] : QO[2 + k], l < Lq));
+        }
+        pl.end();
+    }
+    pl.plain(GS_TD3_LOSS);
+    for (int j = Lq; j >= 1; --j) {
+        pl.begin(1);
+        for (int k = 0; k < 2; ++k) {
+            const GenLayer &L = g->net[1 + k].L[j];
+            pl.add(gen_bwd(j == Lq ? d.DQ[k] : dQZ[k][j], n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
+        }
+        pl.end();
+    }
+    pl.begin(2);
+    for (int k = 0; k < 2; ++k)
+        for (int l = Lq; l >= 0; --l) {
+            const GenLayer &L = g->net[1 + k].L[l];
+            pl.add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, L.N, L.K, g->net[1 + k].G + L.offW, g->net[1 + k].G + L.offB));
+        }
+    pl.end();
+    pl.plain(GS_ADAM);
+    // ---- the actor pass (and its forward half for statistics steps) ----
+    for (int full = 1; full >= 0; --full) {
+        pl.list = full ? &g->td3_actor : &g->td3_stats;
+        policy_fwd(0, XL.off_obs, PHP, HDP);
+        pl.plain(GS_TD3_AHEAD);
+        for (int l = 0; l <= Lq; ++l) {                  // Q1(s, policy(s)) through the updated qf1
+            const GenLayer &L = g->net[1].L[l];
+            pl.one(0, gen_fwd(l == 0 ? d.XA : AH[l - 1], n, Wp(1, l), Bp(1, l), L.N, L.K, l < Lq ? AH[l] : QA, l < Lq));
+        }
+        if (full) {
+            for (int j = Lq; j >= 1; --j) {
+                const GenLayer &L = g->net[1].L[j];
+                pl.one(1, gen_bwd(j == Lq ? d.DQA : dAZ[j], n, L.N, Wp(1, j), L.K, 0, L.K, dAZ[j - 1], L.K, AH[j - 1], L.K));
+            }
+            {
+                const GenLayer &L = g->net[1].L[0];
+                pl.one(1, gen_bwd(dAZ[0], n, L.N, Wp(1, 0), L.K, O, A, DAa, A, nullptr, 0));
+            }
+            pl.plain(GS_TD3_POLGRAD);
+            for (int j = Lp; j >= 1; --j) {
+                const GenLayer &L = g->net[0].L[j];
+                pl.one(1, gen_bwd(j == Lp ? d.DHP : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PHP[j - 1], L.K));
+            }
+            pl.begin(2);
+            for (int l = Lp; l >= 0; --l) {
+                const GenLayer &L = g->net[0].L[l];
+                gen::GemmJob Jw = gen_dw(l == Lp ? d.DHP : dPZ[l], l == 0 ? nullptr : PHP[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB);
+                if (l == 0) { Jw.b_slot = 1; Jw.b_off = XL.off_obs; }
+                pl.add(Jw);
+            }
+            pl.end();
+        }
+        pl.plain(GS_ADAM);
+    }
+    return gen_commit_plan(t, pl, {&g->td3_critic, &g->td3_actor, &g->td3_stats});
 }
 
 void gen_destroy(sac_general *g) {
@@ -323,26 +502,28 @@ int gen_download(sac_trainer *t, int net, const float *src, float *flat) {
     return 0;
 }
 
-// one step on minibatch slot S: the launch sequence built by gen_build
-int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j) {
+// one launch list on minibatch slot S
+int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float *S, const SlotLayout &SL, const StepArg &sa,
+                 const gen::AdamArgs &ad) {
     sac_general *g = t->gen;
     hipStream_t s = t->stream;
-    const double tt = (double)(t->adam_t + 1);
-    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
-    sa.pad2 = t->publish_diag ? 2u : 0u;
     gen::GDev &d = g->dev;
-    d.eps1 = t->dev.eps1; d.eps2 = t->dev.eps2;
     const int n = g->n, A = g->A;
     auto blocks = [](long long work, int cap) { const long long b = (work + 255) / 256; return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b)); };
-    SAC_REQUIRE(SL.off_obs == t->ext_layout.off_obs && SL.off_nobs == t->ext_layout.off_nobs && SL.Bt == n,
-                "internal: minibatch slot layout differs from the one the general step was built for");
-    for (const GenStage &st : g->stages) {
+    // (kernels with a thread per (row, action) need ceil(rows / 16) workgroups; their copy of the slot's rows into the input
+    //  matrices spreads over up to 128)
+    auto head_grid = [&](int rows, long long copy_elems) {
+        const unsigned need = (unsigned)((rows + 15) / 16), copy = blocks(copy_elems / 4, 128);
+        return dim3(need > copy ? need : copy);
+    };
+    long long adam_total = ad.n[0] + ad.n[1] + ad.n[2];
+    for (const GenStage &st : list) {
         switch (st.kind) {
         case GS_GEMM: {
             gen::GemmStage gs = st.gs;
             gs.S = S;
 #ifdef SAC_STAMPS
-            { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - g->stages.data())) ? 1 : 0; }
+            { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - list.data())) ? 1 : 0; }
 #endif
             const dim3 grid(gs.ntiles * gs.splitk);
             if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), grid, dim3(256), 0, s, gs);
@@ -350,17 +531,45 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j)
             else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), grid, dim3(256), 0, s, gs);
             break;
         }
-        case GS_HEAD: {         // (its rows need 2n threads; the copy of the slot's rows into the Q nets' input spreads over up to 128 workgroups)
-            const unsigned need = (unsigned)((2 * n + 15) / 16), copy = blocks((long long)n * (2 * g->O + A) / 4, 128);
-            hipLaunchKernelGGL(gen::k_g_head, dim3(need > copy ? need : copy), dim3(256), 0, s, d, S, SL, sa);
-            break;
-        }
+        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, head_grid(2 * n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
         case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
         case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
-        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(1 + blocks(g->adam_total, 2048)), dim3(256), 0, s, d, g->adam, sa); break;
+        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(1 + (adam_total ? blocks(adam_total, 2048) : 0)), dim3(256), 0, s, d, ad, sa); break;
+        case GS_TD3_HEAD: hipLaunchKernelGGL(gen::k_g_td3_head, head_grid(n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
+        case GS_TD3_LOSS: hipLaunchKernelGGL(gen::k_g_td3_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
+        case GS_TD3_AHEAD: hipLaunchKernelGGL(gen::k_g_td3_ahead, head_grid(n, (long long)n * g->O), dim3(256), 0, s, d, S, SL); break;
+        case GS_TD3_POLGRAD: hipLaunchKernelGGL(gen::k_g_td3_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
         }
     }
     SAC_HIP(hipGetLastError());
+    return 0;
+}
+
+// one step on minibatch slot S.  SAC: the launch list built by gen_build.  TD3 (rlkit TD3Trainer.train_from_torch, as
+// launch_step_td3): the critic pass every step -- its Adam launch also soft-updates the critics' targets on policy steps --
+// and the actor pass on policy steps (n_train_steps_total % policy_and_target_update_period == 0: Q1(s, policy(s)) through the
+// ALREADY UPDATED qf1, policy backward, policy Adam + soft update of the target policy); want_stats on another step: the
+// actor pass's forward half only, for Policy Loss / Policy Action (rlkit recomputes them for the epoch statistics).
+int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, bool want_stats) {
+    sac_general *g = t->gen;
+    SAC_REQUIRE(SL.off_obs == t->ext_layout.off_obs && SL.off_nobs == t->ext_layout.off_nobs && SL.Bt == g->n,
+                "internal: minibatch slot layout differs from the one the general step was built for");
+    g->dev.eps1 = t->dev.eps1; g->dev.eps2 = t->dev.eps2;
+    const double tt = (double)(t->adam_t + 1);
+    StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
+    sa.pad2 = t->publish_diag ? 2u : 0u;
+    if (t->algo == 0) {
+        if (gen_run_list(t, g->stages, S, SL, sa, g->adam)) return -1;
+    } else {
+        const bool pstep = (t->n_train_steps_total % t->td3_period) == 0, actor = pstep || want_stats;
+        const double tp = (double)(t->adam_t_pi + 1);
+        StepArg sp{t->n_train_steps_total, t->adam_t_pi + 1, j, 2, 1.0 - std::pow(0.9, tp), std::sqrt(1.0 - std::pow(0.999, tp))};
+        sp.pad2 = sa.pad2;
+        sa.pad = 1;
+        if (gen_run_list(t, g->td3_critic, S, SL, sa, pstep ? g->adam_q_tp : g->adam_q)) return -1;
+        if (actor && gen_run_list(t, pstep ? g->td3_actor : g->td3_stats, S, SL, sp, pstep ? g->adam_pi : g->adam_none)) return -1;
+        if (pstep) t->adam_t_pi += 1;
+    }
     t->n_train_steps_total += 1;
     t->adam_t += 1;
     return 0;
@@ -372,12 +581,25 @@ int64_t gen_debug_fetch(sac_trainer *t, const std::string &nm, float *out, int64
     const gen::GDev &d = g->dev;
     const int64_t n = g->n, nA = (int64_t)g->n * g->A;
     struct V { const char *name; const float *p; int64_t cnt; };
+    if (t->algo == 1) {
+        const V tv[] = {{"a_next", d.a2, nA}, {"a_new", d.pa, nA}, {"q1", d.QO[0], n}, {"q2", d.QO[1], n}, {"tq1", d.QO[2], n},
+                        {"tq2", d.QO[3], n}, {"q_target", d.y, n}, {"q1_new", d.QA, n},
+                        {"diag_trace", d.diag_trace, (int64_t)DIAG_TRACE_CAP * SAC_DIAG_N}};
+        for (const V &v : tv)
+            if (nm == v.name) {
+                const int64_t cnt = nm == "diag_trace" && cap < v.cnt ? cap : v.cnt;
+                if (cap < cnt) { sac::set_error("buffer too small"); return -2; }
+                if (hipMemcpyAsync(out, v.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, t->stream) != hipSuccess ||
+                    hipStreamSynchronize(t->stream) != hipSuccess) { sac::set_error("copy failed in sac_debug_fetch"); return -1; }
+                return cnt;
+            }
+    }
     const V vs[] = {{"a_new", d.anew, nA}, {"mu", d.mu, nA}, {"log_std", d.ls, nA}, {"a_next", d.a2, nA},
                     {"log_pi", d.logpi, n}, {"log_pi_next", d.logpi2, n}, {"q1", d.QO[0], n}, {"q2", d.QO[1], n},
                     {"q1_new", d.QO[0] + n, n}, {"q2_new", d.QO[1] + n, n}, {"tq1", d.QO[2], n}, {"tq2", d.QO[3], n},
                     {"q_target", d.y, n}, {"diag_trace", d.diag_trace, (int64_t)DIAG_TRACE_CAP * SAC_DIAG_N}};
     for (const V &v : vs)
-        if (nm == v.name) {
+        if (t->algo == 0 && nm == v.name) {
             const int64_t cnt = nm == "diag_trace" && cap < v.cnt ? cap : v.cnt;
             if (cap < cnt) { sac::set_error("buffer too small"); return -2; }
             if (hipMemcpyAsync(out, v.p, sizeof(float) * cnt, hipMemcpyDeviceToHost, t->stream) != hipSuccess ||

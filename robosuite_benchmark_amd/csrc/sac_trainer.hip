@@ -1933,7 +1933,7 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
 // between the launches (profiling pass only)
 
 int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hipEvent_t *ev = nullptr, bool want_stats = false) {
-    if (t->gen) return gen_launch_step(t, S, SL, j);
+    if (t->gen) return gen_launch_step(t, S, SL, j, want_stats);
     if (t->algo == 1) return launch_step_td3(t, S, SL, j, want_stats);
     const Dev &d = t->dev;
     hipStream_t s = t->stream;
@@ -2446,6 +2446,57 @@ int sac_trainer_create_mlp(sac_trainer_t **out, const sac_config_t *cfg, const i
     for (int i = 0; i < n_policy_hidden; ++i) hp[i] = policy_hidden[i];
     for (int i = 0; i < n_qf_hidden; ++i) hq[i] = qf_hidden[i];
     if (trainer_common_init(t, cfg) || gen_build(t, hp, n_policy_hidden, hq, n_qf_hidden) || trainer_prime_events(t)) {
+        sac_trainer_destroy(t);
+        return -1;
+    }
+    *out = t;
+    return 0;
+}
+
+// TD3 with hidden_sizes of any depth (sac_hip.h): the fused kernels' shapes through td3_trainer_create, everything else on
+// the general step (gen_build_td3)
+int td3_trainer_create_mlp(sac_trainer_t **out, const td3_config_t *c, const int32_t *policy_hidden, int32_t n_policy_hidden,
+                           const int32_t *qf_hidden, int32_t n_qf_hidden) {
+    SAC_REQUIRE(out && c && policy_hidden && qf_hidden, "null argument to td3_trainer_create_mlp");
+    *out = nullptr;
+    SAC_REQUIRE(n_policy_hidden >= 1 && n_policy_hidden < gen::GMAXL && n_qf_hidden >= 1 && n_qf_hidden < gen::GMAXL,
+                "%d / %d hidden layers unsupported: 1..%d per network", n_policy_hidden, n_qf_hidden, gen::GMAXL - 1);
+    bool fits = n_policy_hidden == 2 && n_qf_hidden == 2;
+    for (int i = 0; i < n_policy_hidden; ++i) {
+        SAC_REQUIRE(policy_hidden[i] >= 1 && policy_hidden[i] <= 4096, "policy hidden size %d unsupported (1..4096)", policy_hidden[i]);
+        fits = fits && policy_hidden[i] <= H;
+    }
+    for (int i = 0; i < n_qf_hidden; ++i) {
+        SAC_REQUIRE(qf_hidden[i] >= 1 && qf_hidden[i] <= 4096, "qf hidden size %d unsupported (1..4096)", qf_hidden[i]);
+        fits = fits && qf_hidden[i] <= H;
+    }
+    const char *force = getenv("SAC_GENERAL");
+    if (fits && !(force && atoi(force) == 1)) {
+        td3_config_t cc = *c;
+        for (int i = 0; i < 2; ++i) { cc.policy_hidden[i] = policy_hidden[i]; cc.qf_hidden[i] = qf_hidden[i]; }
+        return td3_trainer_create(out, &cc);
+    }
+    SAC_REQUIRE(sac_device_count() > 0, "no HIP device visible: libsac_hip has no CPU fallback");
+    SAC_REQUIRE(c->policy_and_target_update_period > 0, "policy_and_target_update_period must be positive");
+    SAC_REQUIRE(c->target_policy_noise >= 0.f && c->target_policy_noise_clip >= 0.f, "negative target policy noise");
+    SAC_REQUIRE(c->obs_dim > 0 && c->act_dim > 0 && c->act_dim <= 16, "unsupported dims obs=%d act=%d (act_dim must be in 1..16)",
+                c->obs_dim, c->act_dim);
+    SAC_REQUIRE(c->obs_dim <= 496, "obs_dim %d unsupported (the minibatch slots hold cat(obs, act) rows of at most 512 columns)", c->obs_dim);
+    SAC_REQUIRE(c->batch > 0, "batch size %d must be positive", c->batch);
+    SAC_HIP(hipSetDevice(c->device));
+    sac_config_t s{};
+    s.obs_dim = c->obs_dim; s.act_dim = c->act_dim; s.hidden = c->hidden; s.batch = c->batch;
+    s.discount = c->discount; s.reward_scale = c->reward_scale;
+    s.policy_lr = c->policy_learning_rate; s.qf_lr = c->qf_learning_rate;
+    s.soft_target_tau = c->tau; s.target_update_period = 1; s.use_automatic_entropy_tuning = 0;
+    s.target_entropy = 0.f; s.noise_seed = c->noise_seed; s.device = c->device;
+    sac_trainer *t = new sac_trainer();
+    t->algo = 1;
+    t->td3_period = c->policy_and_target_update_period;
+    int hp[gen::GMAXL], hq[gen::GMAXL];
+    for (int i = 0; i < n_policy_hidden; ++i) hp[i] = policy_hidden[i];
+    for (int i = 0; i < n_qf_hidden; ++i) hq[i] = qf_hidden[i];
+    if (trainer_common_init(t, &s) || gen_build_td3(t, c, hp, n_policy_hidden, hq, n_qf_hidden) || trainer_prime_events(t)) {
         sac_trainer_destroy(t);
         return -1;
     }

@@ -34,22 +34,21 @@ class TD3Trainer(SACTrainer):
                          use_automatic_entropy_tuning=False, target_entropy=0.0, batch_size=batch_size,
                          noise_seed=noise_seed, device=device)
 
-    def _hidden(self, net):
-        """TD3 runs on the fused kernels only: two hidden layers of at most 256 units (rlkit_utils.py:108-117 builds them so)."""
-        hs = [int(h) for h in getattr(self, net).hidden_sizes]
-        if len(hs) != 2 or not all(1 <= h <= 256 for h in hs):
-            raise RuntimeError(f"hidden_sizes {hs} unsupported for TD3: two hidden layers of at most 256 units each "
-                               "(SACTrainer takes any depth / width)")
-        return hs
-
     def _new_handle(self, batch):
+        hp, hq = self._hidden("policy"), self._hidden("qf1")
         cfg = Td3Config(self.obs_dim, self.act_dim, 256, batch, self.discount, self.reward_scale,
                         self.policy_learning_rate, self.qf_learning_rate, self.tau, self.target_policy_noise,
                         self.target_policy_noise_clip, self.policy_and_target_update_period, self.noise_seed,
-                        self.device, 0, (C.c_int32 * 2)(*self._hidden("policy")), (C.c_int32 * 2)(*self._hidden("qf1")))
+                        self.device, 0, (C.c_int32 * 2)(0, 0), (C.c_int32 * 2)(0, 0))
         h = C.c_void_p()
-        _lib.check(self._lib.td3_trainer_create(C.byref(h), C.byref(cfg)), "td3_trainer_create")
+        _lib.check(self._lib.td3_trainer_create_mlp(C.byref(h), C.byref(cfg), (C.c_int32 * len(hp))(*hp), len(hp),
+                                                    (C.c_int32 * len(hq))(*hq), len(hq)), "td3_trainer_create_mlp")
         return h
+
+    def _create(self, batch):
+        if self._hidden("target_policy") != self._hidden("policy"):
+            raise RuntimeError("policy and target_policy must share their hidden_sizes (rlkit_utils.py:108-117 builds them so)")
+        super()._create(batch)
 
     @property
     def networks(self):

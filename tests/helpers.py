@@ -92,11 +92,12 @@ def make_td3_pair(O, A, B, seed=3, device=0, **kw):
     from robosuite_benchmark_amd import FlattenMlp, TanhMlpPolicy, TD3Trainer
     kw.setdefault("policy_learning_rate", 1e-3)
     kw.setdefault("qf_learning_rate", 5e-4)
-    nets = init_td3_params(O, A, seed=seed)
+    hidden = tuple(kw.pop("hidden", (256, 256)))
+    nets = init_td3_params(O, A, hidden=hidden, seed=seed)
     noise_seed = kw.pop("noise_seed", 0)
     oracle = RlkitEquivalentTD3(nets, A, **kw)
-    pols = [TanhMlpPolicy([256, 256], A, O) for _ in range(2)]
-    qs = [FlattenMlp([256, 256], 1, O + A) for _ in range(4)]
+    pols = [TanhMlpPolicy(list(hidden), A, O) for _ in range(2)]
+    qs = [FlattenMlp(list(hidden), 1, O + A) for _ in range(4)]
     for p, name in zip(pols, ("policy", "target_policy")):
         p.load_flat(flat_of(nets[name]))
     for q, name in zip(qs, ("qf1", "qf2", "target_qf1", "target_qf2")):

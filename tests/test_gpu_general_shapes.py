@@ -173,3 +173,71 @@ def test_trainer_kwargs_reach_the_general_step(kw, B):
     for name in ("target_qf1", "target_qf2"):           # Polyak: applied on the steps the period says, with the tau given
         assert rel_err(st["params"][name], flat_of(after[name])) < 2e-5, name
     assert abs(st["scalars"][5] - float(oracle.log_alpha.exp().detach() if oracle.auto_alpha else 1.0)) < 1e-6
+
+
+# ---- TD3 on the general step (td3_trainer_create_mlp) -------------------------------------------------------------------
+@pytest.mark.parametrize("hidden,task,B", [((512, 512), "Lift", 256), ((256, 256, 256), "Door", 100), ((300,), "TwoArmLift", 64),
+                                           ((400, 300), "Wipe", 32)])
+def test_td3_steps_against_the_oracle(hidden, task, B):
+    """TD3 with other hidden_sizes: five steps with the delayed policy / target updates against oracle/td3_step_torch.py
+    (parity unpinned beyond it, as for every TD3 number), intermediates and gradients of the first (policy) step."""
+    from tests.helpers import make_td3_pair
+    from tests.test_gpu_td3 import batch_and_noise as td3_batch, check_diag as td3_check
+    O, A = TASK_DIMS[task]
+    oracle, hip = make_td3_pair(O, A, B, seed=11, hidden=hidden, policy_and_target_update_period=2)
+    assert hip.fused_mode() == 3
+    for s_ in range(5):
+        nb, eps = td3_batch(B, O, A, seed=300 + s_)
+        want = oracle.step(nb["observations"], nb["actions"], nb["rewards"], nb["terminals"], nb["next_observations"], eps)
+        diag = hip.train(nb, eps=eps)
+        td3_check(diag, want)                        # (host batches ask for the statistics: the policy entries are current)
+        if s_:
+            continue
+        L = oracle.last
+        for name, ref in (("a_next", L["noisy"]), ("a_new", L["pa"])):
+            assert scale_err(hip.debug_fetch(name, B * A), ref.detach().numpy().ravel()) < 2e-5, name
+        for name, ref in (("q1", L["q1"]), ("q2", L["q2"]), ("q_target", L["y"]), ("tq1", L["tq1"]), ("tq2", L["tq2"]),
+                          ("q1_new", L["q_pi"])):
+            assert rel_err(hip.debug_fetch(name, B), ref.detach().numpy().ravel()) < 2e-5, name
+        for g_ in ("g_qf1", "g_qf2", "g_policy"):
+            assert scale_err(hip.debug_fetch(g_, L[g_].size), L[g_]) < 5e-5, g_
+    nets, got = oracle.export_nets(), hip.state_dict()
+    for name, lr in (("qf1", 5e-4), ("qf2", 5e-4), ("policy", 1e-3)):
+        d = np.abs(got["params"][name] - flat_of(nets[name]))
+        assert np.quantile(d, 0.999) < 0.05 * lr and d.max() < 10 * lr, (name, d.max())
+    for name in ("target_qf1", "target_qf2", "target_policy"):
+        assert np.max(np.abs(got["params"][name] - flat_of(nets[name]))) < 5e-5, name
+    assert got["scalars"][0] == 3 and got["scalars"][3] == got["scalars"][4] == 5       # policy steps 0, 2, 4
+
+
+def test_td3_general_loop_stepwise_and_the_fused_kernels(monkeypatch):
+    """The TD3 general step behind the loop and the stepwise interface (bitwise one trajectory), and against the fused
+    kernels on [256, 256] (SAC_GENERAL=1), same device noise stream: within fp32 round-off."""
+    from tests.helpers import make_td3_pair
+    from tests.test_gpu_fused_step import _buffer
+    O, A, B = 46, 7, 128
+    a, b = (make_td3_pair(O, A, B, seed=3, noise_seed=4, hidden=(320, 160))[1] for _ in range(2))
+    ba, bb = _buffer(4000, O, A, 3), _buffer(4000, O, A, 3)
+    ba.seed(2); bb.seed(2)
+    n = 21
+    _, la = a.train_loop(ba, n, batch_size=B)
+    for _ in range(n):
+        b.train(bb.random_batch(B))
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    assert np.array_equal(sa["scalars"], sb["scalars"])
+    _, fast = make_td3_pair(O, A, B, seed=3, noise_seed=4)
+    monkeypatch.setenv("SAC_GENERAL", "1")
+    _, gen = make_td3_pair(O, A, B, seed=3, noise_seed=4)
+    monkeypatch.delenv("SAC_GENERAL")
+    assert gen.fused_mode() == 3 and fast.fused_mode() != 3
+    bf, bg = _buffer(4000, O, A, 3), _buffer(4000, O, A, 3)
+    bf.seed(8); bg.seed(8)
+    ff, lf = fast.train_loop(bf, 10, batch_size=B)
+    fg, lg = gen.train_loop(bg, 10, batch_size=B)
+    assert np.allclose(ff, fg, rtol=2e-5, atol=2e-5) and np.allclose(lf, lg, rtol=2e-4, atol=2e-4), (np.abs(ff - fg).max(), np.abs(lf - lg).max())
+    pf, pg = fast.state_dict()["params"], gen.state_dict()["params"]
+    for k in pf:
+        d = np.abs(pf[k] - pg[k])
+        assert np.quantile(d, 0.999) < 1e-4 and d.max() < 1e-2, (k, d.max())

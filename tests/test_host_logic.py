@@ -146,7 +146,7 @@ def test_rank_to_task_assignment():
 
 def test_hidden_sizes_any_depth_are_accepted_by_the_sac_holder_and_bounded():
     """variant['policy_kwargs'|'qf_kwargs']['hidden_sizes'] (arguments.py:98,104): SACTrainer takes 1..7 hidden layers of
-    1..4096 units (two of <= 256: the fused kernels, anything else: the general step); TD3 keeps the fused kernels' shapes."""
+    1..4096 units (two of <= 256: the fused kernels, anything else: the general step); so does TD3Trainer."""
     import pytest
     from robosuite_benchmark_amd import FlattenMlp, SACTrainer, TanhGaussianPolicy, TanhMlpPolicy, TD3Trainer
 
@@ -164,5 +164,7 @@ def test_hidden_sizes_any_depth_are_accepted_by_the_sac_holder_and_bounded():
     pols = [TanhMlpPolicy([256, 256, 256], 3, 10, rs=np.random.RandomState(2)) for _ in range(2)]
     qs = [FlattenMlp([256, 256], 1, 13, rs=np.random.RandomState(3)) for _ in range(4)]
     td3 = TD3Trainer(policy=pols[0], qf1=qs[0], qf2=qs[1], target_qf1=qs[2], target_qf2=qs[3], target_policy=pols[1])
-    with pytest.raises(RuntimeError, match="unsupported for TD3"):
-        td3._hidden("policy")
+    assert td3._hidden("policy") == [256, 256, 256] == td3._hidden("target_policy") and td3._hidden("qf1") == [256, 256]
+    td3.target_policy = TanhMlpPolicy([256, 256], 3, 10, rs=np.random.RandomState(2))
+    with pytest.raises(RuntimeError, match="share their hidden_sizes"):
+        td3._create(32)
