@@ -241,3 +241,23 @@ def test_td3_general_loop_stepwise_and_the_fused_kernels(monkeypatch):
     for k in pf:
         d = np.abs(pf[k] - pg[k])
         assert np.quantile(d, 0.999) < 1e-4 and d.max() < 1e-2, (k, d.max())
+
+
+def test_general_trainers_share_a_gpu_and_move_between_xcds():
+    """Two general trainers on one buffer taking turns (no fused gate involved), and one of them confined to the CUs of two
+    XCDs (sac_trainer_set_xcd_mask: a stream swap -- the general step has no residency requirement): the confined run is
+    the same trajectory bit for bit."""
+    from tests.test_gpu_fused_step import _buffer
+    from robosuite_benchmark_amd import _lib
+    O, A, B = 42, 7, 64
+    a, b = (make_pair(O, A, B, seed=2, noise_seed=6, hidden=(300, 300))[1] for _ in range(2))
+    _lib.check(b._lib.sac_trainer_set_xcd_mask(b._h, 0x3), "sac_trainer_set_xcd_mask")
+    ba, bb = _buffer(2000, O, A, 4), _buffer(2000, O, A, 4)
+    ba.seed(1); bb.seed(1)
+    for _ in range(3):
+        la = a.train_loop(ba, 7, batch_size=B)[1]
+        lb = b.train_loop(bb, 7, batch_size=B)[1]
+        assert np.array_equal(la, lb)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
