@@ -13,10 +13,10 @@
 //                [obs|act ; obs|a_new ; next_obs|a']; its last workgroup: mean(log_pi) -> Adam step on log_alpha
 //   k_g_loss     min over the twin nets, Bellman target, the loss gradients of the four Q passes that have one
 //   k_g_polgrad  head gradient of the reparameterised actor loss
-//   k_g_adam     Adam on every trained parameter + Polyak average of the targets (flat vectors); one workgroup of it
-//                computes the diagnostics vector
+//   k_g_diag     the diagnostics vector (Adam and the Polyak average run in the weight-gradient launch's epilogue: a tile's
+//                owner updates the parameters it owns)
 // Weights live in nn.Linear layout (W [out][in] row-major, then b), activations row-major [row][feature]; rows = the
-// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 8 launches per step (16 for two hidden layers): this path is for
+// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 7 launches per step (15 for two hidden layers; + one for the diagnostics on the steps somebody reads them): this path is for
 // shapes the reference can be configured with but no shipped variant uses -- the shipped ones take the fused kernels.
 #pragma once
 
@@ -39,6 +39,11 @@ struct GemmJob {
     int M, N, R;
     int relu, ones_col, tiles_n, tile0, a_slot, b_slot;
     int a_vec, b_vec, pad_;         // the operand may be fetched in 16-byte pieces (alignment and extents checked by the host)
+    // weight-gradient jobs: the tile's owner applies torch.optim.Adam (and the Polyak average of the target) in its epilogue --
+    // C is the layer's slice of the gradient vector, these are the same slice of the parameter / moment / target vectors
+    // (aX: the weights, bX: the bias behind the column of ones); null: a plain product
+    float *aP, *aM, *aV, *aTP, *bP, *bM, *bV, *bTP;
+    float lr; int pad2_;
 };
 struct GemmStage {                  // kernel argument: the jobs of one launch (device array) + their first tiles
     const GemmJob *jobs;
@@ -51,6 +56,10 @@ struct GemmStage {                  // kernel argument: the jobs of one launch (
     int splitk;
     float *scratch;
     unsigned *tile_cnt;
+    // the optimizer step of a weight-gradient launch (host state, as StepArg): bias corrections, Polyak this step?, keep the
+    // gradient vector (sac_debug_fetch "g_*": the steps whose caller reads the diagnostics)?
+    double bc1, bc2s;
+    float tau; int polyak, keep_grad, pad3_;
     int njobs, ntiles;
     int tile0[GMAXJ];
 };
@@ -83,13 +92,6 @@ struct GDev {
     float *DQA;                     // its loss gradient (-1/n) [n]
     const float *DAa;               // dL/da through Q1 [n][A]
     float *DHP;                     // head gradient [n][A]
-};
-
-struct AdamArgs {
-    float *P[3], *M[3], *V[3], *TP[3];
-    const float *G[3];
-    long long n[3];
-    float lr[3];
 };
 
 // ------------------------------------------------------------------------------------------
@@ -304,6 +306,50 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
             for (int k = 1; k < 4; ++k) if (k < splitk) acc[t] += part[k][t];
         }
     }
+    if constexpr (!A_RC && !B_RC) {
+        if (J.aP) {     // a weight-gradient tile: Adam (+ Polyak) on the parameters it owns; the gradient never round-trips through HBM
+            const unsigned ldc = (unsigned)J.ldc;
+            const bool polyak = T.polyak && J.aTP;
+            const float step_size = (float)((double)J.lr / T.bc1), bc2s = (float)T.bc2s;
+            float pv[4][4], mv[4][4], vv[4][4], tv[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = n0 + 16 * t + c;
+                const bool ones = has_ones && n == J.N;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned mc = (unsigned)min(m0 + 16 * wave + 4 * g + i, J.M - 1);
+                    const unsigned off = ones ? mc : mc * ldc + (unsigned)min(n, J.N - 1);
+                    pv[t][i] = ld1g((ones ? J.bP : J.aP) + off);
+                    mv[t][i] = ld1g((ones ? J.bM : J.aM) + off);
+                    vv[t][i] = ld1g((ones ? J.bV : J.aV) + off);
+                    tv[t][i] = polyak ? ld1g((ones ? J.bTP : J.aTP) + off) : 0.f;
+                }
+            }
+            SB();
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = n0 + 16 * t + c;
+                const bool ones = has_ones && n == J.N;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + 16 * wave + 4 * g + i;
+                    if (m >= J.M || !(n < J.N || ones)) continue;
+                    const unsigned off = ones ? (unsigned)m : (unsigned)m * ldc + (unsigned)n;
+                    float p = pv[t][i], mm = mv[t][i], v = vv[t][i];
+                    adam_update(p, mm, v, acc[t][i], step_size, bc2s);
+                    typedef __attribute__((address_space(1))) float gfloat;
+                    *(gfloat *)(uintptr_t)((ones ? J.bP : J.aP) + off) = p;
+                    *(gfloat *)(uintptr_t)((ones ? J.bM : J.aM) + off) = mm;
+                    *(gfloat *)(uintptr_t)((ones ? J.bV : J.aV) + off) = v;
+                    if (T.keep_grad) *(gfloat *)(uintptr_t)((ones ? J.c_ones : J.C) + off) = acc[t][i];
+                    if (polyak) *(gfloat *)(uintptr_t)((ones ? J.bTP : J.aTP) + off) = tv[t][i] * (1.0f - T.tau) + p * T.tau;
+                }
+            }
+            GSTAMP(7);
+            return;
+        }
+    }
     // epilogue: every load up front (clamped, unconditional, pinned in front of the arithmetic), stores through global
     // pointers at 32-bit offsets, one predicate per element -- written with early-outs and conditional loads it compiled to
     // a branch and a full wait per element: 2.2 us of a forward launch, 4.7 us of a masked one (in-kernel stamps)
@@ -477,25 +523,11 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
 __device__ void diag_block(const GDev &d, const StepArg &sa);
 __device__ void td3_diag_block(const GDev &d, const StepArg &sa);
 
-// torch.optim.Adam on the three trained networks (flat vectors) + ptu.soft_update_from_to of the two targets; workgroup 0
-// computes the step's diagnostics instead (it reads nothing this launch writes)
-__global__ __launch_bounds__(256) void k_g_adam(GDev d, AdamArgs P, StepArg sa) {
-    if (blockIdx.x == 0) {          // (SAC: the diagnostics of the steps somebody reads -- the first and the last of a loop, single steps)
-        if (d.algo == 1) td3_diag_block(d, sa);
-        else if ((sa.pad2 & 2u) || sa.loop_pos == 0) diag_block(d, sa);
-        return;
-    }
-    const bool polyak = (sa.step_now % d.period) == 0;
-    const float bc2s = (float)sa.bc2s;
-    const long long tot = P.n[0] + P.n[1] + P.n[2];
-    for (long long e = (long long)(blockIdx.x - 1) * 256 + threadIdx.x; e < tot; e += (long long)(gridDim.x - 1) * 256) {
-        const int k = e < P.n[0] ? 0 : (e < P.n[0] + P.n[1] ? 1 : 2);
-        const long long i = e - (k > 0 ? P.n[0] : 0) - (k > 1 ? P.n[1] : 0);
-        float p = P.P[k][i], m = P.M[k][i], v = P.V[k][i];
-        adam_update(p, m, v, P.G[k][i], (float)((double)P.lr[k] / sa.bc1), bc2s);
-        P.P[k][i] = p; P.M[k][i] = m; P.V[k][i] = v;
-        if (polyak && P.TP[k]) P.TP[k][i] = P.TP[k][i] * (1.0f - d.tau) + p * d.tau;
-    }
+// the step's diagnostics (one workgroup): launched on the steps somebody reads them (SAC) / behind every pass (TD3, whose
+// vector keeps the most recent value of each entry)
+__global__ __launch_bounds__(256) void k_g_diag(GDev d, StepArg sa) {
+    if (d.algo == 1) td3_diag_block(d, sa);
+    else diag_block(d, sa);
 }
 
 // the diagnostics vector (SURVEY Appendix A line 17); one workgroup, sums in double

@@ -12,23 +12,19 @@ struct GenNet {
 };
 constexpr int GEN_MAX_JOBS = 16 * gen::GMAXJ;
 struct GenStage { int kind = 0, mode = 0; size_t base = 0; gen::GemmStage gs{}; };   // mode: 0 forward, 1 backward, 2 weight gradients   // kind 0: a k_g_gemm launch; else see launch
-enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_ADAM, GS_TD3_HEAD, GS_TD3_LOSS, GS_TD3_AHEAD, GS_TD3_POLGRAD };
+enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_DIAG, GS_TD3_HEAD, GS_TD3_LOSS, GS_TD3_AHEAD, GS_TD3_POLGRAD };
 
 struct sac_general {
     int n = 0, O = 0, A = 0, Lp = 0, Lq = 0;
     int hp[gen::GMAXL] = {}, hq[gen::GMAXL] = {};
     GenNet net[6];                                    // 5: TD3's target policy
     gen::GDev dev{};
-    gen::AdamArgs adam{};
-    // TD3: the critic pass (every step), the actor pass (policy steps), the actor pass's forward half (statistics steps);
-    // Adam on the critics without / with the Polyak targets, on the policy (+ target policy), on nothing (statistics only)
+    // TD3: the critic pass (every step), the actor pass (policy steps), the actor pass's forward half (statistics steps)
     std::vector<GenStage> td3_critic, td3_actor, td3_stats;
-    gen::AdamArgs adam_q{}, adam_q_tp{}, adam_pi{}, adam_none{};
     char *arena = nullptr;
     gen::GemmJob *d_jobs = nullptr;
     float *d_scratch = nullptr; unsigned *d_tile_cnt = nullptr;      // split reductions (sac_general.h: GemmStage::splitk)
     std::vector<GenStage> stages;
-    long long adam_total = 0;
 };
 
 namespace {
@@ -96,13 +92,17 @@ gen::GemmJob gen_bwd(const float *dY, int M, int Nl, const float *W, int K, int 
     J.M = M; J.N = ncols; J.R = Nl;
     return J;
 }
-// dW = dY^T X over `rows` rows, db = column sums of dY: dY [rows][Nl], X [rows][K]
-gen::GemmJob gen_dw(const float *dY, const float *X, int rows, int Nl, int K, float *GW, float *Gb) {
+// dW = dY^T X over `rows` rows, db = column sums of dY (dY [rows][Nl], X [rows][K]) for layer L of net N, whose owner tiles
+// apply Adam at learning rate lr and the Polyak average into `target` (null: none) in their epilogue
+gen::GemmJob gen_dw(const float *dY, const float *X, int rows, const GenNet &N, const GenLayer &L, float lr, const GenNet *target) {
     gen::GemmJob J = gen_job_zero();
-    J.A = dY; J.sa_m = 1; J.sa_r = Nl;
-    J.Bm = X; J.sb_n = 1; J.sb_r = K;
-    J.C = GW; J.ldc = K; J.c_ones = Gb; J.ones_col = 1;
-    J.M = Nl; J.N = K; J.R = rows;
+    J.A = dY; J.sa_m = 1; J.sa_r = L.N;
+    J.Bm = X; J.sb_n = 1; J.sb_r = L.K;
+    J.C = N.G + L.offW; J.ldc = L.K; J.c_ones = N.G + L.offB; J.ones_col = 1;
+    J.M = L.N; J.N = L.K; J.R = rows;
+    J.aP = N.P + L.offW; J.aM = N.M + L.offW; J.aV = N.V + L.offW; J.aTP = target ? target->P + L.offW : nullptr;
+    J.bP = N.P + L.offB; J.bM = N.M + L.offB; J.bV = N.V + L.offB; J.bTP = target ? target->P + L.offB : nullptr;
+    J.lr = lr;
     return J;
 }
 
@@ -230,14 +230,7 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
     d.diag_dev = t->d_diag;
     d.eps1 = d.eps2 = nullptr;
-    gen::AdamArgs &ad = g->adam;
     const float lrs[3] = {cfg.policy_lr, cfg.qf_lr, cfg.qf_lr};
-    for (int k = 0; k < 3; ++k) {
-        ad.P[k] = g->net[k].P; ad.M[k] = g->net[k].M; ad.V[k] = g->net[k].V; ad.G[k] = g->net[k].G;
-        ad.TP[k] = k == 0 ? nullptr : g->net[k + 2].P;
-        ad.n[k] = g->net[k].n; ad.lr[k] = lrs[k];
-        g->adam_total += g->net[k].n;
-    }
 
     // ---- the launch sequence ----
     GenPlanner pl;
@@ -304,18 +297,17 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
     begin(2);                                             // every weight gradient of the step
     for (int l = Lp; l >= 0; --l) {
         const GenLayer &L = g->net[0].L[l];
-        gen::GemmJob Jw = gen_dw(l == Lp ? d.DHD : dPZ[l], l == 0 ? nullptr : PH[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB);
+        gen::GemmJob Jw = gen_dw(l == Lp ? d.DHD : dPZ[l], l == 0 ? nullptr : PH[l - 1], n, g->net[0], L, lrs[0], nullptr);
         if (l == 0) { Jw.b_slot = 1; Jw.b_off = XL.off_obs; }
         add(Jw);
     }
     for (int k = 0; k < 2; ++k)
         for (int l = Lq; l >= 0; --l) {
             const GenLayer &L = g->net[1 + k].L[l];
-            add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, L.N, L.K,
-                       g->net[1 + k].G + L.offW, g->net[1 + k].G + L.offB));
+            add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, g->net[1 + k], L, lrs[1 + k], &g->net[3 + k]));
         }
     end();
-    plain(GS_ADAM);
+    plain(GS_DIAG);
     return gen_commit_plan(t, pl, {&g->stages});
 }
 
@@ -378,21 +370,6 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
     d.diag_first = t->d_diag_host; d.diag_last = t->d_diag_host + SAC_DIAG_N; d.diag_trace = t->d_diag + 2 * SAC_DIAG_N;
     d.diag_dev = t->d_diag;
     d.eps1 = d.eps2 = nullptr;
-    auto adam_of = [&](gen::AdamArgs &ad, std::initializer_list<int> nets, bool with_targets, float lr) {
-        ad = gen::AdamArgs{};
-        int k = 0;
-        for (int i : nets) {
-            ad.P[k] = g->net[i].P; ad.M[k] = g->net[i].M; ad.V[k] = g->net[i].V; ad.G[k] = g->net[i].G;
-            ad.TP[k] = with_targets ? g->net[i == 0 ? 5 : i + 2].P : nullptr;
-            ad.n[k] = g->net[i].n; ad.lr[k] = lr;
-            ++k;
-        }
-    };
-    adam_of(g->adam_q, {1, 2}, false, c->qf_learning_rate);
-    adam_of(g->adam_q_tp, {1, 2}, true, c->qf_learning_rate);
-    adam_of(g->adam_pi, {0}, true, c->policy_learning_rate);
-    adam_of(g->adam_none, {}, false, 0.f);
-
     GenPlanner pl;
     const SlotLayout &XL = t->ext_layout;
     auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
@@ -435,10 +412,10 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
     for (int k = 0; k < 2; ++k)
         for (int l = Lq; l >= 0; --l) {
             const GenLayer &L = g->net[1 + k].L[l];
-            pl.add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, L.N, L.K, g->net[1 + k].G + L.offW, g->net[1 + k].G + L.offB));
+            pl.add(gen_dw(l == Lq ? d.DQ[k] : dQZ[k][l], l == 0 ? d.XQ : QH[k][l - 1], n, g->net[1 + k], L, c->qf_learning_rate, &g->net[3 + k]));
         }
     pl.end();
-    pl.plain(GS_ADAM);
+    pl.plain(GS_DIAG);
     // ---- the actor pass (and its forward half for statistics steps) ----
     for (int full = 1; full >= 0; --full) {
         pl.list = full ? &g->td3_actor : &g->td3_stats;
@@ -465,13 +442,13 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
             pl.begin(2);
             for (int l = Lp; l >= 0; --l) {
                 const GenLayer &L = g->net[0].L[l];
-                gen::GemmJob Jw = gen_dw(l == Lp ? d.DHP : dPZ[l], l == 0 ? nullptr : PHP[l - 1], n, L.N, L.K, g->net[0].G + L.offW, g->net[0].G + L.offB);
+                gen::GemmJob Jw = gen_dw(l == Lp ? d.DHP : dPZ[l], l == 0 ? nullptr : PHP[l - 1], n, g->net[0], L, c->policy_learning_rate, &g->net[5]);
                 if (l == 0) { Jw.b_slot = 1; Jw.b_off = XL.off_obs; }
                 pl.add(Jw);
             }
             pl.end();
         }
-        pl.plain(GS_ADAM);
+        pl.plain(GS_DIAG);
     }
     return gen_commit_plan(t, pl, {&g->td3_critic, &g->td3_actor, &g->td3_stats});
 }
@@ -503,8 +480,9 @@ int gen_download(sac_trainer *t, int net, const float *src, float *flat) {
 }
 
 // one launch list on minibatch slot S
+// (polyak: the weight-gradient launch of this list also soft-updates the targets of the nets it trains)
 int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float *S, const SlotLayout &SL, const StepArg &sa,
-                 const gen::AdamArgs &ad) {
+                 bool polyak) {
     sac_general *g = t->gen;
     hipStream_t s = t->stream;
     gen::GDev &d = g->dev;
@@ -516,12 +494,12 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
         const unsigned need = (unsigned)((rows + 15) / 16), copy = blocks(copy_elems / 4, 128);
         return dim3(need > copy ? need : copy);
     };
-    long long adam_total = ad.n[0] + ad.n[1] + ad.n[2];
     for (const GenStage &st : list) {
         switch (st.kind) {
         case GS_GEMM: {
             gen::GemmStage gs = st.gs;
             gs.S = S;
+            gs.bc1 = sa.bc1; gs.bc2s = sa.bc2s; gs.tau = d.tau; gs.polyak = polyak ? 1 : 0; gs.keep_grad = (sa.pad2 & 2u) ? 1 : 0;
 #ifdef SAC_STAMPS
             { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - list.data())) ? 1 : 0; }
 #endif
@@ -534,7 +512,9 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
         case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, head_grid(2 * n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
         case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
         case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
-        case GS_ADAM: hipLaunchKernelGGL(gen::k_g_adam, dim3(1 + (adam_total ? blocks(adam_total, 2048) : 0)), dim3(256), 0, s, d, ad, sa); break;
+        case GS_DIAG:       // (SAC: on the steps whose diagnostics somebody reads -- the first and the last of a loop, single steps)
+            if (t->algo == 1 || (sa.pad2 & 2u) || sa.loop_pos == 0) hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa);
+            break;
         case GS_TD3_HEAD: hipLaunchKernelGGL(gen::k_g_td3_head, head_grid(n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
         case GS_TD3_LOSS: hipLaunchKernelGGL(gen::k_g_td3_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
         case GS_TD3_AHEAD: hipLaunchKernelGGL(gen::k_g_td3_ahead, head_grid(n, (long long)n * g->O), dim3(256), 0, s, d, S, SL); break;
@@ -559,15 +539,15 @@ int gen_launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
     StepArg sa{t->n_train_steps_total, t->adam_t + 1, j, 0, 1.0 - std::pow(0.9, tt), std::sqrt(1.0 - std::pow(0.999, tt))};
     sa.pad2 = t->publish_diag ? 2u : 0u;
     if (t->algo == 0) {
-        if (gen_run_list(t, g->stages, S, SL, sa, g->adam)) return -1;
+        if (gen_run_list(t, g->stages, S, SL, sa, (t->n_train_steps_total % g->dev.period) == 0)) return -1;
     } else {
         const bool pstep = (t->n_train_steps_total % t->td3_period) == 0, actor = pstep || want_stats;
         const double tp = (double)(t->adam_t_pi + 1);
         StepArg sp{t->n_train_steps_total, t->adam_t_pi + 1, j, 2, 1.0 - std::pow(0.9, tp), std::sqrt(1.0 - std::pow(0.999, tp))};
         sp.pad2 = sa.pad2;
         sa.pad = 1;
-        if (gen_run_list(t, g->td3_critic, S, SL, sa, pstep ? g->adam_q_tp : g->adam_q)) return -1;
-        if (actor && gen_run_list(t, pstep ? g->td3_actor : g->td3_stats, S, SL, sp, pstep ? g->adam_pi : g->adam_none)) return -1;
+        if (gen_run_list(t, g->td3_critic, S, SL, sa, pstep)) return -1;
+        if (actor && gen_run_list(t, pstep ? g->td3_actor : g->td3_stats, S, SL, sp, true)) return -1;
         if (pstep) t->adam_t_pi += 1;
     }
     t->n_train_steps_total += 1;
