@@ -261,3 +261,22 @@ def test_general_trainers_share_a_gpu_and_move_between_xcds():
     sa, sb = a.state_dict(), b.state_dict()
     for k in sa["params"]:
         assert np.array_equal(sa["params"][k], sb["params"][k]), k
+
+
+@pytest.mark.parametrize("hidden,hidden_q,O,A,B", [((1,), (1,), 5, 2, 16), ((32,) * 7, (48,) * 7, 30, 4, 40), ((4096,), (2048, 3), 42, 7, 8),
+                                                     ((260, 4), (4, 260), 496, 16, 24), ((513, 257), (255, 511), 17, 1, 33)])
+def test_extreme_shapes_against_the_oracle(hidden, hidden_q, O, A, B):
+    """The corners of what sac_trainer_create_mlp accepts: one unit, seven layers, 4096 units, the widest observation and
+    action the slots hold, odd widths around the tile and vector sizes -- two steps against the oracle."""
+    oracle, hip = make_pair(O, A, B, seed=9, hidden=hidden, hidden_q=hidden_q)
+    assert hip.fused_mode() == 3
+    for s_ in range(2):
+        np_batch, eps = batch_and_noise(B, O, A, seed=40 + s_, term_frac=0.1)
+        want = oracle.step(np_batch["observations"], np_batch["actions"], np_batch["rewards"], np_batch["terminals"],
+                           np_batch["next_observations"], *eps)
+        check_diag(hip.train(np_batch, eps=eps), want, tol=1e-4 if s_ else TOL)
+    L = oracle.last
+    for key in ("g_policy", "g_qf1", "g_qf2"):
+        ws, bs = L[key][:len(L[key]) // 2], L[key][len(L[key]) // 2:]
+        ref = np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(ws, bs)])
+        assert scale_err(hip.debug_fetch(key, ref.size), ref) < 1e-4, key
