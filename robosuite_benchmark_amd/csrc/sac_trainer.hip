@@ -767,6 +767,10 @@ __global__ __launch_bounds__(256) void k_fwd_b(Dev d, const float *__restrict__ 
     // SAC: Q1, Q2 on (s,a_new); T1, T2 on (s',a').  TD3 critic pass: b % 8 in {0..3} -> T1, {4..7} -> T2.  TD3 actor: Q1.
     const int p4 = (MODE == M_SAC) ? (xr >> 1) : (MODE == M_TD3_CRITIC ? 2 + (xr >> 2) : 0);
     const int b = (MODE == M_SAC) ? 2 * xq + (xr & 1) : (MODE == M_TD3_CRITIC ? 4 * xq + (xr & 3) : (int)blockIdx.x);
+    // (TD3 critic pass: groups of four blocks per twin -- the grid is rounded up to whole groups, the blocks beyond the last
+    //  row-block leave.  Round 2 launched 2 SP NB blocks whatever SP NB was: with SP NB % 4 == 2 the last two row-blocks of
+    //  twin 2 were never computed and twin 1 ran two row-blocks past the batch -- found by scratch/fuzz_fused.py in round 3)
+    if (MODE == M_TD3_CRITIC && b >= SP * NB) return;
     const int part = b % SP, rb = b / SP;
     const int side = p4 >> 1, pass = 2 + p4;
     const int row0 = rb * RB;
@@ -1263,12 +1267,14 @@ __device__ __forceinline__ void policy_bwd_block(const Dev &d, const StepArg &sa
 // Block -> work map.  Three equal groups of SP*NB blocks: critic Q1, critic Q2, policy.  While they fit one
 // per CU on six XCDs (3*SP*NB <= 192) the map is XCD-aware (b % 8 in {0,1} -> Q1, {2,3} -> Q2, {4,5} -> policy,
 // {6,7} idle: an XCD's L2 pulls one network's transposed weights); larger batches use every CU instead.
-// MODE M_TD3_CRITIC: critic blocks only (grid 2*SP*NB; b % 8 in {0..3} -> Q1, {4..7} -> Q2); M_TD3_ACTOR: policy blocks only.
+// MODE M_TD3_CRITIC: critic blocks only (grid: whole groups of eight, b % 8 in {0..3} -> Q1, {4..7} -> Q2); M_TD3_ACTOR: policy blocks only.
 template <int NTH, int SP, int MODE = M_SAC>
 __global__ __launch_bounds__(256) void k_bwd(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa, int compact) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     if constexpr (MODE == M_TD3_CRITIC) {
-        critic_bwd_block<SP, MODE>(d, S, SL, sa, (blockIdx.x & 7) >> 2, 4 * (blockIdx.x >> 3) + (blockIdx.x & 3));
+        const int bq = 4 * (blockIdx.x >> 3) + (blockIdx.x & 3);
+        if (bq >= SP * d.NB) return;         // (grid rounded up to whole groups of four blocks per twin: see k_fwd_b)
+        critic_bwd_block<SP, MODE>(d, S, SL, sa, (blockIdx.x & 7) >> 2, bq);
     } else if constexpr (MODE == M_TD3_ACTOR) {
         policy_bwd_block<NTH, SP, MODE>(d, sa, blockIdx.x);
     } else {
@@ -1908,8 +1914,9 @@ int launch_step_td3(sac_trainer *t, const float *S, const SlotLayout &SL, int j,
         if (launch_fused_abc(t, S, SL, sq, actor ? 4u : 0u)) return -1;
     } else {
         hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, actor ? 1 : 0);
-        hipLaunchKernelGGL(t->fwd_b, dim3(2 * SPv * NB), dim3(256), t->lds_fb, s, d, S, SL, sq);
-        hipLaunchKernelGGL(t->bwd, dim3(2 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
+        const unsigned g2 = 8u * (unsigned)((SPv * NB + 3) / 4);      // two twins x groups of four blocks (k_fwd_b / k_bwd, TD3 critic map)
+        hipLaunchKernelGGL(t->fwd_b, dim3(g2), dim3(256), t->lds_fb, s, d, S, SL, sq);
+        hipLaunchKernelGGL(t->bwd, dim3(g2), dim3(256), t->lds_bw, s, d, S, SL, sq, 0);
     }
     const DwTable &Tq = pstep ? t->dw_q_tp : t->dw_q;
     hipLaunchKernelGGL(k_dw_adam, dim3(Tq.njobs + 1), dim3(256), 0, s, d, Tq, S, sq);

@@ -27,7 +27,10 @@ def scale_err(got, want):
     return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / max(1e-30, np.max(np.abs(want))))
 
 
-@pytest.mark.parametrize("O,A,B", [(42, 7, 256), (46, 7, 1024), (89, 14, 256), (379, 6, 64), (11, 3, 512), (5, 2, 16)])
+# (992, 334, 1328: SP * NB % 4 == 2 -- the TD3 critic launches' groups of four blocks per twin end in a partial group there;
+#  round 2 mis-mapped it, found by scratch/fuzz_fused.py in round 3)
+@pytest.mark.parametrize("O,A,B", [(42, 7, 256), (46, 7, 1024), (89, 14, 256), (379, 6, 64), (11, 3, 512), (5, 2, 16),
+                                   (49, 5, 992), (97, 14, 334), (40, 11, 1328), (300, 13, 1095)])
 def test_policy_step_from_identical_state(O, A, B):
     oracle, hip = make_td3_pair(O, A, B, seed=11)
     nb, eps = batch_and_noise(B, O, A, seed=21)
