@@ -113,6 +113,7 @@ struct GenPlanner {
     GenStage cur;
     long long scratch_floats = 0;
     int max_tiles = 0;
+    bool overflow = false;                  // a launch with more jobs than its table holds (checked by gen_commit_plan)
     void begin(int mode) {
         cur = GenStage{};
         cur.kind = GS_GEMM; cur.mode = mode; cur.base = jobs.size();
@@ -127,6 +128,7 @@ struct GenPlanner {
                         : (aligned && s_row == 1 && s_red % 4 == 0 && rows % 4 == 0 && rows >= 4));
     }
     void add(gen::GemmJob J) {
+        if (cur.gs.njobs >= gen::GMAXJ) { overflow = true; return; }
         J.a_vec = vec_ok(J.A, J.a_off, J.a_slot != 0, J.sa_m, J.sa_r, J.M, J.R, cur.mode != 2);
         J.b_vec = vec_ok(J.Bm, J.b_off, J.b_slot != 0, J.sb_n, J.sb_r, J.N, J.R, cur.mode == 0);
         J.tiles_n = (J.N + (J.ones_col ? 1 : 0) + gen::GT - 1) / gen::GT;
@@ -155,7 +157,8 @@ struct GenPlanner {
 // the planner's jobs to the device, the split reductions' scratch, the lists' device pointers
 int gen_commit_plan(sac_trainer *t, GenPlanner &pl, std::initializer_list<std::vector<GenStage> *> lists) {
     sac_general *g = t->gen;
-    SAC_REQUIRE(pl.jobs.size() <= (size_t)GEN_MAX_JOBS, "internal: %zu matrix-product jobs", pl.jobs.size());
+    SAC_REQUIRE(pl.jobs.size() <= (size_t)GEN_MAX_JOBS && !pl.overflow, "internal: %zu matrix-product jobs%s", pl.jobs.size(),
+                pl.overflow ? " (a launch's job table overflowed)" : "");
     SAC_HIP(hipMemcpyAsync(g->d_jobs, pl.jobs.data(), sizeof(gen::GemmJob) * pl.jobs.size(), hipMemcpyHostToDevice, t->stream));
     if (pl.scratch_floats) SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_scratch), sizeof(float) * (size_t)pl.scratch_floats));
     SAC_HIP(hipMalloc(reinterpret_cast<void **>(&g->d_tile_cnt), sizeof(unsigned) * (size_t)(pl.max_tiles + 1)));
