@@ -27,6 +27,9 @@ constexpr int GMAXJ = 24;           // jobs of one launch (the weight-gradient l
 constexpr int GT = 64;              // output tile (rows and columns)
 constexpr int GLD = GT + 4;         // LDS row stride of a staged operand chunk
 constexpr int GK = 64;              // reduction chunk
+constexpr int GW = 8;               // waves of a workgroup: two per SIMD (one wave's LDS reads and address arithmetic under the other's MFMAs)
+constexpr int GE = GT * GK / (64 * GW);   // values of an operand's chunk per thread (8)
+constexpr int GNT = 16 / GW;        // 16 x 16 output tiles per wave (2): row tile wave & 3, column tiles GNT (wave >> 2) + t
 
 struct GemmJob {
     const float *A;                 // A(m, r) = A[m sa_m + r sa_r]
@@ -97,17 +100,17 @@ struct GDev {
 // ------------------------------------------------------------------------------------------
 // the matrix-product kernel
 // ------------------------------------------------------------------------------------------
-// A workgroup owns a 64 x 64 tile of C; wave w its rows 16 w .. 16 w + 15 (four 16 x 16 MFMA accumulators).  The reduction
-// runs in chunks of 64: each thread fetches 16 values per operand (a wave reads 256 contiguous bytes along whichever
+// A workgroup (eight waves: two per SIMD) owns a 64 x 64 tile of C; wave w the row tile w & 3 and two of the four column
+// tiles (two 16 x 16 MFMA accumulators).  The reduction runs in chunks of 64: each thread fetches 8 values per operand (a wave reads 256 contiguous bytes along whichever
 // direction the operand is contiguous in), the chunk goes to LDS as [slow][fast] -- [row][r] for an operand that is
 // contiguous along the reduction, [r][row] otherwise: conflict-free writes either way -- and the next chunk's loads are in
-// flight while this one's 64 MFMAs per wave run.  The MFMA with index i of k-group (q, g) contracts r = 16 q + 4 g + i for
+// flight while this one's 32 MFMAs per wave run.  The MFMA with index i of k-group (q, g) contracts r = 16 q + 4 g + i for
 // both operands, so an operand stored [row][r] is read with one 16-byte LDS load per four MFMAs.
-// One operand's share of a chunk in one thread: 16 values v[k] at chunk coordinates (slow, fast) -- for an operand that is
+// One operand's share of a chunk in one thread: 8 values v[k] at chunk coordinates (slow, fast) -- for an operand that is
 // contiguous along the reduction (RC) that is (row, r), else (r, row); the chunk sits in LDS as [slow][fast].
-//   scalar map: slow = wave + 4 k, fast = lane               (16 dword loads, a wave reads 256 contiguous bytes)
-//   vector map: slow = (tid >> 4) + 16 (k >> 2), fast = 4 (tid & 15) + (k & 3)
-//               (4 loads of 16 bytes, 4 LDS writes of 16 bytes: when base, row stride and extent along `fast` allow it)
+//   scalar map: slow = wave + 8 k, fast = lane               (8 dword loads, a wave reads 256 contiguous bytes)
+//   vector map: slow = (tid >> 4) + 32 (k >> 2), fast = 4 (tid & 15) + (k & 3)
+//               (2 loads of 16 bytes, 2 LDS writes of 16 bytes: when base, row stride and extent along `fast` allow it)
 // Loads are UNCONDITIONAL from clamped indices -- a row beyond the matrix repeats the last one (its products land in
 // outputs that are never stored), the reduction's padding is zeroed in the edge chunk only -- and go through explicitly
 // GLOBAL pointers.  Both matter: a conditional load is a branch whose merge point waits for the data, and a generic
@@ -119,11 +122,11 @@ struct GOperand {
     const float *P;
     int sx, sr, X, R, x0, ones_x;     // strides (floats), rows, reduction length, the tile's first row, local row of ones (-1: none)
     bool vec;
-    unsigned off[16];
-    float v[16];
+    unsigned off[GE];
+    float v[GE];
     __device__ __forceinline__ int slow_of(int k) const {
         const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        return vec ? (tid >> 4) + 16 * (k >> 2) : wv + 4 * k;
+        return vec ? (tid >> 4) + 4 * GW * (k >> 2) : wv + GW * k;
     }
     __device__ __forceinline__ int fast_of(int k) const {
         const int tid = threadIdx.x;
@@ -134,11 +137,11 @@ struct GOperand {
     }
     __device__ __forceinline__ void init() {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) off[k] = RC ? addr(slow_of(k), fast_of(k)) : addr(fast_of(k), slow_of(k));
+        for (int k = 0; k < GE; ++k) off[k] = RC ? addr(slow_of(k), fast_of(k)) : addr(fast_of(k), slow_of(k));
         // (vector map, k = 4 j: the 16 bytes at off[4 j]; an operand that is contiguous along its rows clamps whole vectors)
         if (vec && !RC) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) off[4 * j] = (unsigned)(min(x0 + fast_of(4 * j), X - 4) * sx + min(slow_of(4 * j), R - 1) * sr);
+            for (int j = 0; j < GE / 4; ++j) off[4 * j] = (unsigned)(min(x0 + fast_of(4 * j), X - 4) * sx + min(slow_of(4 * j), R - 1) * sr);
         }
     }
     __device__ __forceinline__ void fetch(int s) {
@@ -147,20 +150,20 @@ struct GOperand {
             const float *cb = P + (long long)r0 * sr;                       // uniform
             if (vec) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < GE / 4; ++j) {
                     const f32x4 q = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(cb + off[4 * j]);
                     v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = ld1g(cb + off[k]);
+                for (int k = 0; k < GE; ++k) v[k] = ld1g(cb + off[k]);
             }
             return;
         }
         // the edge chunk: reduction indices clamped (their products are zeroed by fix); whole vectors stay inside R (R % 4 == 0)
         if (vec) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < GE / 4; ++j) {
                 const unsigned o = RC ? (unsigned)(min(x0 + slow_of(4 * j), X - 1) * sx + min(r0 + fast_of(4 * j), R - 4) * sr)
                                       : (unsigned)(min(x0 + fast_of(4 * j), X - 4) * sx + min(r0 + slow_of(4 * j), R - 1) * sr);
                 const f32x4 q = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(P + o);
@@ -168,7 +171,7 @@ struct GOperand {
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = ld1g(P + (RC ? addr(slow_of(k), r0 + fast_of(k)) : addr(fast_of(k), r0 + slow_of(k))));
+            for (int k = 0; k < GE; ++k) v[k] = ld1g(P + (RC ? addr(slow_of(k), r0 + fast_of(k)) : addr(fast_of(k), r0 + slow_of(k))));
         }
     }
     // behind the loads' arrival, in front of the LDS writes: the row of ones, the reduction's zero padding.  (A vector that
@@ -178,20 +181,20 @@ struct GOperand {
         const int r0 = GK * s;
         if (ones_x >= 0) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if ((RC ? slow_of(k) : fast_of(k)) == ones_x) v[k] = 1.0f;
+            for (int k = 0; k < GE; ++k) if ((RC ? slow_of(k) : fast_of(k)) == ones_x) v[k] = 1.0f;
         }
         if (r0 + GK > R) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (r0 + (RC ? fast_of(k) : slow_of(k)) >= R) v[k] = 0.f;
+            for (int k = 0; k < GE; ++k) if (r0 + (RC ? fast_of(k) : slow_of(k)) >= R) v[k] = 0.f;
         }
     }
     __device__ __forceinline__ void write(float *lds) const {
         if (vec) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) st4(lds + slow_of(4 * j) * GLD + fast_of(4 * j), f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]});
+            for (int j = 0; j < GE / 4; ++j) st4(lds + slow_of(4 * j) * GLD + fast_of(4 * j), f32x4{v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]});
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) lds[slow_of(k) * GLD + fast_of(k)] = v[k];
+            for (int k = 0; k < GE; ++k) lds[slow_of(k) * GLD + fast_of(k)] = v[k];
         }
     }
 };
@@ -200,7 +203,7 @@ struct GOperand {
 // (true, true), backward through a layer (true, false), weight gradient (false, false).  Only the thread -> element map
 // and the LDS layout depend on it; the addresses always use the job's strides.
 template <bool A_RC, bool B_RC>
-__global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
+__global__ __launch_bounds__(64 * GW) void k_g_gemm(GemmStage T) {
     __shared__ __attribute__((aligned(16))) float As[GT * GLD], Bs[GT * GLD];
     const int splitk = T.splitk, tile_lin = (int)blockIdx.x / splitk, ks = (int)blockIdx.x - tile_lin * splitk;
     int li = 0;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     const int tile = tile_lin - J.tile0;
     const int m0 = GT * (tile / J.tiles_n), n0 = GT * (tile % J.tiles_n);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int rt = wave & 3, ct0 = GNT * (wave >> 2);          // this wave's row tile and its first column tile
     constexpr bool a_rc = A_RC, b_rc = B_RC;
     GOperand<a_rc> oa;
     GOperand<b_rc> ob;
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
-    f32x4 acc[4] = {};
+    f32x4 acc[GNT] = {};
     const int nSall = (J.R + GK - 1) / GK;
     const int sfirst = (ks * nSall) / splitk, nS = ((ks + 1) * nSall) / splitk;       // this workgroup's chunks [sfirst, nS)
     GSTAMP(0);
@@ -248,34 +252,34 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
         if (s == 1) GSTAMP(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 a, b[4];
-            if constexpr (a_rc) a = ld4(As + (16 * wave + c) * GLD + 16 * q + 4 * g);
+            f32x4 a, b[GNT];
+            if constexpr (a_rc) a = ld4(As + (16 * rt + c) * GLD + 16 * q + 4 * g);
             else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = As[(16 * q + 4 * g + i) * GLD + 16 * wave + c];
+                for (int i = 0; i < 4; ++i) a[i] = As[(16 * q + 4 * g + i) * GLD + 16 * rt + c];
             }
             if constexpr (b_rc) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b[t] = ld4(Bs + (16 * t + c) * GLD + 16 * q + 4 * g);
+                for (int t = 0; t < GNT; ++t) b[t] = ld4(Bs + (16 * (ct0 + t) + c) * GLD + 16 * q + 4 * g);
             } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < GNT; ++t)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) b[t][i] = Bs[(16 * q + 4 * g + i) * GLD + 16 * t + c];
+                    for (int i = 0; i < 4; ++i) b[t][i] = Bs[(16 * q + 4 * g + i) * GLD + 16 * (ct0 + t) + c];
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
+                for (int t = 0; t < GNT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[t][i], acc[t], 0, 0, 0);
         }
-        if (s == 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); GSTAMP(5); }
+        if (s == 1) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[GNT - 1][3])); GSTAMP(5); }
     }
     GSTAMP(6);
     if (splitk > 1) {
         __shared__ unsigned am_last;
         float *mine = T.scratch + ((size_t)tile_lin * splitk + ks) * (GT * GT);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) st4_sc1(mine + (t * 256 + tid) * 4, acc[t]);
+        for (int t = 0; t < GNT; ++t) st4_sc1(mine + (t * 64 * GW + tid) * 4, acc[t]);
         // (the hand-off protocol of the fused step, sac_fused.h: write-through stores, every wave waits for its own, a
         //  workgroup barrier, ONE relaxed agent-scope increment -- a __threadfence() / an acq_rel atomic here writes the
         //  whole L2 back and invalidates it: 27 us per launch, measured)
@@ -292,15 +296,15 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
         //  increment, and this workgroup touches these lines for the first time in a launch that began with invalidated
         //  caches)
         const float *all = T.scratch + (size_t)tile_lin * splitk * (GT * GT);
-        f32x4 part[4][4];
+        f32x4 part[4][GNT];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                part[k][t] = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(all + (size_t)(k < splitk ? k : 0) * (GT * GT) + (t * 256 + tid) * 4);
+            for (int t = 0; t < GNT; ++t)
+                part[k][t] = *(const __attribute__((address_space(1))) f32x4 *)(uintptr_t)(all + (size_t)(k < splitk ? k : 0) * (GT * GT) + (t * 64 * GW + tid) * 4);
         SB();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < GNT; ++t) {
             acc[t] = part[0][t];
 #pragma unroll
             for (int k = 1; k < 4; ++k) if (k < splitk) acc[t] += part[k][t];
@@ -311,14 +315,14 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
             const unsigned ldc = (unsigned)J.ldc;
             const bool polyak = T.polyak && J.aTP;
             const float step_size = (float)((double)J.lr / T.bc1), bc2s = (float)T.bc2s;
-            float pv[4][4], mv[4][4], vv[4][4], tv[4][4];
+            float pv[GNT][4], mv[GNT][4], vv[GNT][4], tv[GNT][4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n = n0 + 16 * t + c;
+            for (int t = 0; t < GNT; ++t) {
+                const int n = n0 + 16 * (ct0 + t) + c;
                 const bool ones = has_ones && n == J.N;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const unsigned mc = (unsigned)min(m0 + 16 * wave + 4 * g + i, J.M - 1);
+                    const unsigned mc = (unsigned)min(m0 + 16 * rt + 4 * g + i, J.M - 1);
                     const unsigned off = ones ? mc : mc * ldc + (unsigned)min(n, J.N - 1);
                     pv[t][i] = ld1g((ones ? J.bP : J.aP) + off);
                     mv[t][i] = ld1g((ones ? J.bM : J.aM) + off);
@@ -328,12 +332,12 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
             }
             SB();
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int n = n0 + 16 * t + c;
+            for (int t = 0; t < GNT; ++t) {
+                const int n = n0 + 16 * (ct0 + t) + c;
                 const bool ones = has_ones && n == J.N;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + 16 * wave + 4 * g + i;
+                    const int m = m0 + 16 * rt + 4 * g + i;
                     if (m >= J.M || !(n < J.N || ones)) continue;
                     const unsigned off = ones ? (unsigned)m : (unsigned)m * ldc + (unsigned)n;
                     float p = pv[t][i], mm = mv[t][i], v = vv[t][i];
@@ -353,15 +357,15 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     // epilogue: every load up front (clamped, unconditional, pinned in front of the arithmetic), stores through global
     // pointers at 32-bit offsets, one predicate per element -- written with early-outs and conditional loads it compiled to
     // a branch and a full wait per element: 2.2 us of a forward launch, 4.7 us of a masked one (in-kernel stamps)
-    float bv[4], mk[4][4];
+    float bv[GNT], mk[GNT][4];
     const unsigned ldc = (unsigned)J.ldc, ldm = (unsigned)J.ldmask;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const unsigned nc = (unsigned)min(n0 + 16 * t + c, J.N - 1);
+    for (int t = 0; t < GNT; ++t) {
+        const unsigned nc = (unsigned)min(n0 + 16 * (ct0 + t) + c, J.N - 1);
         bv[t] = ld1g((J.bias ? J.bias : Bp) + (J.bias ? nc : 0u));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned mc = (unsigned)min(m0 + 16 * wave + 4 * g + i, J.M - 1);
+            const unsigned mc = (unsigned)min(m0 + 16 * rt + 4 * g + i, J.M - 1);
             mk[t][i] = ld1g((J.mask ? J.mask : Bp) + (J.mask ? mc * ldm + nc : 0u));
         }
     }
@@ -369,11 +373,11 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     const bool has_bias = J.bias != nullptr, has_mask = J.mask != nullptr;
     float *const Cg = J.C;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int n = n0 + 16 * t + c;
+    for (int t = 0; t < GNT; ++t) {
+        const int n = n0 + 16 * (ct0 + t) + c;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = m0 + 16 * wave + 4 * g + i;
+            const int m = m0 + 16 * rt + 4 * g + i;
             float v = acc[t][i] + (has_bias ? bv[t] : 0.f);
             if (J.relu) v = fmaxf(v, 0.f);
             if (has_mask) v = (mk[t][i] > 0.f) ? v : 0.f;
@@ -382,11 +386,11 @@ __global__ __launch_bounds__(256) void k_g_gemm(GemmStage T) {
     }
     if (has_ones) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (n0 + 16 * t + c == J.N) {
+        for (int t = 0; t < GNT; ++t)
+            if (n0 + 16 * (ct0 + t) + c == J.N) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int m = m0 + 16 * wave + 4 * g + i;
+                    const int m = m0 + 16 * rt + 4 * g + i;
                     if (m < J.M) *(__attribute__((address_space(1))) float *)(uintptr_t)(J.c_ones + m) = acc[t][i];
                 }
             }

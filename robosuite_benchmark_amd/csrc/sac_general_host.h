@@ -507,9 +507,9 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
             { static const char *e = getenv("SAC_GEN_STAMP_STAGE"); gs.stamp = (e && atoi(e) == (int)(&st - list.data())) ? 1 : 0; }
 #endif
             const dim3 grid(gs.ntiles * gs.splitk);
-            if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), grid, dim3(256), 0, s, gs);
-            else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), grid, dim3(256), 0, s, gs);
-            else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), grid, dim3(256), 0, s, gs);
+            if (st.mode == 0) hipLaunchKernelGGL((gen::k_g_gemm<true, true>), grid, dim3(64 * gen::GW), 0, s, gs);
+            else if (st.mode == 1) hipLaunchKernelGGL((gen::k_g_gemm<true, false>), grid, dim3(64 * gen::GW), 0, s, gs);
+            else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), grid, dim3(64 * gen::GW), 0, s, gs);
             break;
         }
         case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, head_grid(2 * n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
