@@ -270,7 +270,7 @@ int sac_train_loop(sac_trainer_t *t, sac_buffer_t *buf, int64_t n_steps, float *
 int sac_trainer_is_fused(const sac_trainer_t *t);
 /* How a trainer's step is launched: 0 = four launches (k_fwd_a, k_fwd_b, k_bwd, k_dw_adam); 1 = the fused step above
  * (k_abc, k_dw_adam: batches up to 256 rows); 2 = three launches for batches whose 256-wide layers are not split over
- * workgroups (1024 rows and more): the two forward launches as ONE, k_chain -- a workgroup runs the policy, takes its own
+ * workgroups (1024 rows and more): the two forward launches as ONE, k_chain8 -- a workgroup runs the policy, takes its own
  * head and goes on into the Q nets, no hand-off involved -- then k_bwd and k_dw_adam; 3 = the general step of
  * sac_trainer_create_mlp (network shapes beyond the fused kernels').  (TD3: 0 or 1.) */
 int sac_trainer_step_kind(const sac_trainer_t *t);

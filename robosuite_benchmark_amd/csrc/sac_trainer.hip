@@ -1772,7 +1772,7 @@ struct sac_trainer {
     void (*bwd)(Dev, const float *, SlotLayout, StepArg, int) = nullptr;
     size_t lds_fa = 0, lds_fb = 0;
     // column split 1 (batch >= 1024): launches A + B as one launch without any hand-off (k_chain, sac_chain.h)
-    bool chain = false;
+    bool chain = false, chain8 = false;               // chain8: the eight-wave variant of k_chain (512 threads per workgroup)
     void (*chaink)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_chain = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
@@ -1956,7 +1956,7 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
         if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); SAC_HIP(hipEventRecord(ev[3], s)); }
     } else {
         if (t->chain) {
-            hipLaunchKernelGGL(t->chaink, dim3(4 * NB), dim3(256), t->lds_chain, s, d, S, SL, sa);
+            hipLaunchKernelGGL(t->chaink, dim3(4 * NB), dim3(t->chain8 ? 512 : 256), t->lds_chain, s, d, S, SL, sa);
             if (ev) { SAC_HIP(hipEventRecord(ev[1], s)); SAC_HIP(hipEventRecord(ev[2], s)); }
         } else {
             hipLaunchKernelGGL(t->fwd_a, dim3(4 * SPv * NB), dim3(256), t->lds_fa, s, d, S, SL, 0);
@@ -2397,6 +2397,10 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         {
             const bool wide4 = t->KQ > 64;       // first layers of more than four k-chunks
             t->chaink = (nth == 1) ? (wide4 ? &k_chain<1, true> : &k_chain<1, false>) : (wide4 ? &k_chain<2, true> : &k_chain<2, false>);
+            const char *e8 = getenv("SAC_CHAIN8");            // (A/B comparisons: 0 = the four-wave kernel)
+            t->chain8 = !(e8 && atoi(e8) == 0);
+            if (t->chain8)
+                t->chaink = (nth == 1) ? (wide4 ? &k_chain8<1, true> : &k_chain8<1, false>) : (wide4 ? &k_chain8<2, true> : &k_chain8<2, false>);
         }
         if (t->chain && t->lds_chain > 64 * 1024)
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->chaink), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -109,3 +109,27 @@ def test_which_batches_take_the_chained_launch():
     for (O, A, B) in [(46, 7, 1024), (86, 14, 1024), (379, 6, 1024), (46, 7, 2048), (46, 7, 512), (42, 7, 256)]:
         kinds[(O, A, B)] = _with_env(dict(SAC_CHAIN=None, SAC_FUSED=None), lambda: make_pair(O, A, B, seed=1)[1]).fused_mode()
     assert kinds == {(46, 7, 1024): 2, (86, 14, 1024): 2, (379, 6, 1024): 0, (46, 7, 2048): 0, (46, 7, 512): 0, (42, 7, 256): 1}
+
+
+@pytest.mark.parametrize("O,A,B", [(46, 7, 1024), (86, 14, 1024), (42, 7, 992), (300, 6, 1024)])
+def test_eight_wave_chain_kernel_is_the_four_wave_one_bit_for_bit(O, A, B, monkeypatch):
+    """k_chain8 (512 threads per workgroup: two 16-column tiles per wave, two waves per SIMD) runs every tile's MFMA sequence
+    and every split-K sum in k_chain's order: same trajectory, bit for bit (SAC_CHAIN8=0 selects the four-wave kernel)."""
+    from tests.test_gpu_fused_step import _buffer
+    monkeypatch.setenv("SAC_CHAIN", "1")
+    monkeypatch.setenv("SAC_CHAIN8", "0")
+    _, four = make_pair(O, A, B, seed=3, noise_seed=5)
+    monkeypatch.setenv("SAC_CHAIN8", "1")
+    _, eight = make_pair(O, A, B, seed=3, noise_seed=5)
+    assert four.fused_mode() == 2 and eight.fused_mode() == 2
+    bufs = [_buffer(5000, O, A, 2), _buffer(5000, O, A, 2)]
+    for b in bufs:
+        b.seed(4)
+    la = four.train_loop(bufs[0], 12, batch_size=B)[1]
+    lb = eight.train_loop(bufs[1], 12, batch_size=B)[1]
+    assert np.array_equal(la, lb)
+    sa, sb = four.state_dict(), eight.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    for k in sa["opt"]:
+        assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
