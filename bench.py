@@ -581,8 +581,10 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc"}.get(dom, dom), workload_tag(task, B))
     pk_m = peaks["fp32_mfma_tflops"] if peaks else None
     whole = sum(fl.values()) * value / world / 1e12
+    # (the kernel's name as rocprofv3's kernel trace prints it)
+    symbol = {"k_fwd_abc": "k_abc", "k_chain": "k_chain" if os.environ.get("SAC_CHAIN8") == "0" else "k_chain8"}.get(dom, dom)
     out["roofline"] = dict(
-        bound="mfma", kernel=dom, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+        bound="mfma", kernel=dom, kernel_symbol=symbol, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
         frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), peak_spec=PEAK_FP32_MFMA_TFLOPS, peak_measured=pk_m,
         frac_measured=round(achieved / pk_m, 5) if pk_m else None, traffic=traffic, traffic_source=traffic_src,
         flops_per_launch=fl[dom], avg_launch_ms=round(dom_ms, 5), exec_ms=round(prof[dom], 5),
