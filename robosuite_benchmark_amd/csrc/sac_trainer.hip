@@ -1699,6 +1699,7 @@ __global__ __launch_bounds__(256) void k_dw_adam(Dev d, DwTable T, const float *
     dw_adam_body(d, T, S, sa, red, redb, trs, (int)blockIdx.x, aborted);
 }
 
+#include "sac_bwd8.h"
 #include "sac_fused.h"
 #include "sac_chain.h"
 #include "sac_general.h"
@@ -1773,6 +1774,7 @@ struct sac_trainer {
     size_t lds_fa = 0, lds_fb = 0;
     // column split 1 (batch >= 1024): launches A + B as one launch without any hand-off (k_chain, sac_chain.h)
     bool chain = false, chain8 = false;               // chain8: the eight-wave variant of k_chain (512 threads per workgroup)
+    bool bwd8 = false;                                // the backward launch at column split 1 on eight waves (k_bwd8, sac_bwd8.h)
     void (*chaink)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_chain = 0;
     long long n_train_steps_total = 0, adam_t = 0;   // host-side step counters (rlkit _n_train_steps_total)
@@ -1965,7 +1967,7 @@ int launch_step(sac_trainer *t, const float *S, const SlotLayout &SL, int j, hip
             if (ev) SAC_HIP(hipEventRecord(ev[2], s));
         }
         const int compact = (3 * SPv * NB <= 192) ? 1 : 0;     // see k_bwd
-        hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(256), t->lds_bw, s, d, S, SL, sa, compact);
+        hipLaunchKernelGGL(t->bwd, dim3(compact ? 4 * SPv * NB : 3 * SPv * NB), dim3(t->bwd8 ? 512 : 256), t->lds_bw, s, d, S, SL, sa, compact);
         if (ev) SAC_HIP(hipEventRecord(ev[3], s));
     }
     if (ev) SAC_HIP(hipEventRecord(ev[4], s));
@@ -2401,6 +2403,11 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
             t->chain8 = !(e8 && atoi(e8) == 0);
             if (t->chain8)
                 t->chaink = (nth == 1) ? (wide4 ? &k_chain8<1, true> : &k_chain8<1, false>) : (wide4 ? &k_chain8<2, true> : &k_chain8<2, false>);
+        }
+        {   // column split 1, SAC: the backward launch on eight waves too (SAC_BWD8=0: the four-wave kernel, A/B comparisons)
+            const char *eb = getenv("SAC_BWD8");
+            t->bwd8 = !td3 && t->SP == 1 && !(eb && atoi(eb) == 0);
+            if (t->bwd8) t->bwd = (nth == 1) ? &k_bwd8<1> : &k_bwd8<2>;
         }
         if (t->chain && t->lds_chain > 64 * 1024)
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->chaink), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,16 +1,17 @@
-"""k_chain8 (eight waves) against k_chain (four): the same bits; and the step rate of both.  usage: python scratch/chain8_check.py"""
+"""k_chain8 / k_bwd8 (eight waves) against k_chain / k_bwd (four): the same bits; and the step rate of both.
+usage: python scratch/chain8_check.py [SAC_CHAIN8|SAC_BWD8]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.helpers import make_pair
 from tests.test_gpu_fused_step import _buffer
-for (O, A, B) in ((46, 7, 1024), (86, 14, 1024), (42, 7, 992), (30, 16, 800)):
+KNOB = sys.argv[1] if len(sys.argv) > 1 else "SAC_CHAIN8"
+for (O, A, B) in ((46, 7, 1024), (86, 14, 1024), (42, 7, 992), (30, 16, 800), (46, 7, 2048), (379, 6, 1024)):
     trs = []
     for e in ("0", "1"):
-        os.environ["SAC_CHAIN8"] = e
-        os.environ["SAC_CHAIN"] = "1"
+        os.environ[KNOB] = e
         trs.append(make_pair(O, A, B, seed=3, noise_seed=5)[1])
-    os.environ.pop("SAC_CHAIN8"); os.environ.pop("SAC_CHAIN")
+    os.environ.pop(KNOB)
     bufs = [_buffer(6000, O, A, 2), _buffer(6000, O, A, 2)]
     for b in bufs:
         b.seed(4)

@@ -133,3 +133,28 @@ def test_eight_wave_chain_kernel_is_the_four_wave_one_bit_for_bit(O, A, B, monke
         assert np.array_equal(sa["params"][k], sb["params"][k]), k
     for k in sa["opt"]:
         assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
+
+
+@pytest.mark.parametrize("O,A,B", [(46, 7, 1024), (86, 14, 1024), (46, 7, 2048), (379, 6, 1040)])
+def test_eight_wave_backward_kernel_is_the_four_wave_one_bit_for_bit(O, A, B, monkeypatch):
+    """k_bwd8 (column split 1, 512 threads per workgroup) against k_bwd<.., 1>: same trajectory, bit for bit, behind
+    k_chain8 and behind the two forward launches (SAC_BWD8=0 selects the four-wave kernel)."""
+    from tests.test_gpu_fused_step import _buffer
+    monkeypatch.setenv("SAC_BWD8", "0")
+    _, four = make_pair(O, A, B, seed=3, noise_seed=5)
+    monkeypatch.setenv("SAC_BWD8", "1")
+    _, eight = make_pair(O, A, B, seed=3, noise_seed=5)
+    bufs = [_buffer(5000, O, A, 2), _buffer(5000, O, A, 2)]
+    for b in bufs:
+        b.seed(4)
+    la = four.train_loop(bufs[0], 9, batch_size=B)[1]
+    lb = eight.train_loop(bufs[1], 9, batch_size=B)[1]
+    assert np.array_equal(la, lb)
+    sa, sb = four.state_dict(), eight.state_dict()
+    for k in sa["params"]:
+        assert np.array_equal(sa["params"][k], sb["params"][k]), k
+    for k in sa["opt"]:
+        assert np.array_equal(sa["opt"][k][0], sb["opt"][k][0]) and np.array_equal(sa["opt"][k][1], sb["opt"][k][1]), k
+    for name in ("g_policy", "g_qf1", "g_qf2"):
+        n = sa["params"][name[2:]].size
+        assert np.array_equal(four.debug_fetch(name, n), eight.debug_fetch(name, n)), name
