@@ -2389,18 +2389,20 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     {   // column split 1: the forward launches as one (sac_chain.h); SAC_CHAIN=0: the four-launch step (A/B comparisons)
         const char *e = getenv("SAC_CHAIN");
         t->lds_chain = sizeof(float) * (size_t)(RB * KL0q + 2 * RB * H + 4 * nth * 256 + RB * 32);
-        // Where it pays (measured, scripts/large_batch_matrix.sh): one round of workgroups (4 NB <= CUs: batch 1024) and first
-        // layers of at most eight k-chunks -- Door 46/7 58.1 -> 54.8 us per step, TwoArmHandoff 86/14 64.9 -> 64.2; batch 2048
-        // (two rounds of 350-register workgroups) and Wipe's 25-chunk first layers (recomputed by both P items) lose.
+        // Where it pays (measured, scripts/large_batch_matrix.sh; round 3's second half with the eight-wave kernel): first layers
+        // of at most eight k-chunks -- Door 46/7 batch 1024 58.1 -> 51.8 us per step, TwoArmHandoff 86/14 64.9 -> 60.9, and
+        // now batches of more than one round of workgroups too (Door batch 1536 87.7 -> 83.9, batch 2048 95.3 -> 91.7: the
+        // four-wave kernel's 350 registers lost there); Wipe's 25-chunk first layers (recomputed by both P items) still lose
+        // (83.4 against 86.6).
         int cus = 0;
         SAC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device));
-        const bool pays = (4 * t->NB <= cus && t->KQ <= 128) || (e && atoi(e) == 1);
+        const char *e8 = getenv("SAC_CHAIN8");                // (A/B comparisons: 0 = the four-wave kernel)
+        t->chain8 = !(e8 && atoi(e8) == 0);
+        const bool pays = ((t->chain8 || 4 * t->NB <= cus) && t->KQ <= 128) || (e && atoi(e) == 1);
         t->chain = !td3 && !t->fused && t->SP == 1 && (t->NB % 2) == 0 && t->lds_chain <= 160 * 1024 - 512 && pays && !(e && atoi(e) == 0);
         {
             const bool wide4 = t->KQ > 64;       // first layers of more than four k-chunks
             t->chaink = (nth == 1) ? (wide4 ? &k_chain<1, true> : &k_chain<1, false>) : (wide4 ? &k_chain<2, true> : &k_chain<2, false>);
-            const char *e8 = getenv("SAC_CHAIN8");            // (A/B comparisons: 0 = the four-wave kernel)
-            t->chain8 = !(e8 && atoi(e8) == 0);
             if (t->chain8)
                 t->chaink = (nth == 1) ? (wide4 ? &k_chain8<1, true> : &k_chain8<1, false>) : (wide4 ? &k_chain8<2, true> : &k_chain8<2, false>);
         }
