@@ -557,7 +557,8 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     fl_all = flops_per_kernel(B, O, A)
     step_kernels = [k for k in prof if k.startswith("k_") and k not in ("k_gather", "k_mt_randint") and prof[k] > 0]
     # a fused launch carries the FLOPs of the launches it replaces ("k_fwd_abc" = a + b + c ...)
-    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_chain": ("k_fwd_a", "k_fwd_b")}
+    fused_parts = {"k_fwd_abc": ("k_fwd_a", "k_fwd_b", "k_bwd"), "k_chain": ("k_fwd_a", "k_fwd_b"),
+                   "k_chain_bwd": ("k_fwd_a", "k_fwd_b", "k_bwd")}
     fl = {k: (sum(fl_all[p] for p in fused_parts[k]) if k in fused_parts else fl_all[k]) for k in step_kernels}
     kern = {}
     for k, f in fl.items():
@@ -578,11 +579,12 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
     boundary_ms = max(0.0, (step_ms - sum(prof[k] for k in fl)) / len(fl))
     dom_ms = prof[dom] + boundary_ms
     achieved = fl[dom] / (dom_ms * 1e-3) / 1e12
-    traffic, traffic_src = pmc_traffic({"k_fwd_abc": "k_abc"}.get(dom, dom), workload_tag(task, B))
+    # (the kernel's name as rocprofv3's kernel trace prints it)
+    symbol = {"k_fwd_abc": "k_abc", "k_chain": "k_chain" if os.environ.get("SAC_CHAIN8") == "0" else "k_chain8",
+              "k_chain_bwd": "k_chain8"}.get(dom, dom)
+    traffic, traffic_src = pmc_traffic(symbol, workload_tag(task, B))
     pk_m = peaks["fp32_mfma_tflops"] if peaks else None
     whole = sum(fl.values()) * value / world / 1e12
-    # (the kernel's name as rocprofv3's kernel trace prints it)
-    symbol = {"k_fwd_abc": "k_abc", "k_chain": "k_chain" if os.environ.get("SAC_CHAIN8") == "0" else "k_chain8"}.get(dom, dom)
     out["roofline"] = dict(
         bound="mfma", kernel=dom, kernel_symbol=symbol, achieved=round(achieved, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
         frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 5), peak_spec=PEAK_FP32_MFMA_TFLOPS, peak_measured=pk_m,

@@ -272,7 +272,11 @@ int sac_trainer_is_fused(const sac_trainer_t *t);
  * (k_abc, k_dw_adam: batches up to 256 rows); 2 = three launches for batches whose 256-wide layers are not split over
  * workgroups (1024 rows and more): the two forward launches as ONE, k_chain8 -- a workgroup runs the policy, takes its own
  * head and goes on into the Q nets, no hand-off involved -- then k_bwd and k_dw_adam; 3 = the general step of
- * sac_trainer_create_mlp (network shapes beyond the fused kernels').  (TD3: 0 or 1.) */
+ * sac_trainer_create_mlp (network shapes beyond the fused kernels'); 4 = kind 2 with the backward blocks inside the chained
+ * launch behind in-launch hand-offs (k_chain8<..., BWD>, then k_dw_adam: two launches; chosen when the launch's 4 x
+ * row-blocks workgroups fill the CUs exactly -- batch 1024 on 256 CUs -- and the first layers are one k-chunk;
+ * SAC_CHAIN_BWD=0/1 overrides).  Like kind 1 it can give up inside a launch; the trainer then re-runs that step as kind 2
+ * and stays there (sac_trainer_step_kind reports 2 from then on), results unchanged.  (TD3: 0 or 1.) */
 int sac_trainer_step_kind(const sac_trainer_t *t);
 
 /* measurement helpers: HIP events on the trainer's stream around the last sac_train_loop (total_ms == steps_ms: first

@@ -9,6 +9,40 @@ namespace bwd8 {
 
 constexpr int CT = 2, CF = 32;      // 16-column tiles per wave, features per wave
 
+// XW (k_chain8<.., BWD = true>, sac_chain.h): the block runs INSIDE the forward launch, behind in-launch hand-offs -- what
+// another workgroup of the launch wrote (target q values, log pi', the other twin's q_new and action gradient, the row-block
+// sums of log pi) is read through agent-scope loads, and the entropy step sums those sums from vector loads (the scalar
+// cache may hold the previous launch's words); same values, same order: same bits.
+template <bool XW>
+__device__ __forceinline__ float xload(const float *p) { return XW ? ld_sc1(p) : *p; }
+
+// alpha_step with the row-block sums read by vector agent-scope loads, summed in alpha_step's order (NB <= 64 per pass)
+__device__ __forceinline__ AlphaStep alpha_step_xw(const Ctl *ctl, const float *part_logpi, int NB, int B, float target_entropy,
+                                                   float lr, int auto_alpha, double bc1, double bc2s) {
+    AlphaStep r;
+    const float la = sload(&ctl->log_alpha), m0 = sload(&ctl->a_m), v0 = sload(&ctl->a_v);
+    if (!auto_alpha) { r.alpha = 1.0f; r.alpha_loss = 0.0f; r.log_alpha = la; r.m = m0; r.v = v0; return r; }
+    const int lane = threadIdx.x & 63;
+    float sum = 0.f;
+    for (int i0 = 0; i0 < NB; i0 += 64) {
+        const float mine = ld_sc1(part_logpi + (i0 + lane < NB ? i0 + lane : 0));
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            if (i0 + i < NB) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), i));
+    }
+    const float mean_lp = sum / (float)B + target_entropy;
+    r.alpha_loss = -((la * mean_lp) + 0.0f);
+    const float gr = -mean_lp;
+    r.m = m0 + ADAM_1MB1 * (gr - m0);
+    r.v = v0 * ADAM_B2 + ADAM_1MB2 * gr * gr;
+    const float step_size = (float)((double)lr / bc1);
+    const float denom = sqrtf(r.v) / (float)bc2s + 1e-8f;
+    r.log_alpha = la + (-step_size * r.m) / denom;
+    r.alpha = expf(r.log_alpha);
+    return r;
+}
+
+template <bool XW = false>
 __device__ __forceinline__ void critic_block(const Dev &d, const float *__restrict__ S, const SlotLayout &SL, const StepArg &sa,
                                              int qi, int rb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -30,10 +64,10 @@ __device__ __forceinline__ void critic_block(const Dev &d, const float *__restri
     float qa = 0.f, qb = 0.f, qq = 0.f, in_c = 0.f, in_r = 0.f, in_t = 0.f;
     if (threadIdx.x < RB) {
         const int r = row0 + threadIdx.x;
-        qa = d.qpart[(size_t)4 * B + r];
-        qb = d.qpart[(size_t)5 * B + r];
-        qq = d.qpart[(size_t)qi * B + r];
-        in_c = d.logpi2[r];
+        qa = xload<XW>(d.qpart + (size_t)4 * B + r);
+        qb = xload<XW>(d.qpart + (size_t)5 * B + r);
+        qq = xload<XW>(d.qpart + (size_t)qi * B + r);
+        in_c = xload<XW>(d.logpi2 + r);
         in_r = S[SL.off_rew + r]; in_t = S[SL.off_term + r];
     }
     const int k = threadIdx.x & 255;                         // (first four waves: thread = feature k)
@@ -50,7 +84,8 @@ __device__ __forceinline__ void critic_block(const Dev &d, const float *__restri
 #pragma unroll
     for (int t = 0; t < CT; ++t) h1v[t] = ld4(h1T + frag_off(n0 + 16 * t + c, row0 + 4 * g, B));
     SB();
-    const float alpha = alpha_step(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+    const float alpha = XW ? alpha_step_xw(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha
+                           : alpha_step(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     USE_FROM_HERE(qa); USE_FROM_HERE(qb); USE_FROM_HERE(qq);
     USE_FROM_HERE(in_c); USE_FROM_HERE(in_r); USE_FROM_HERE(in_t);
     float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
@@ -99,7 +134,7 @@ __device__ __forceinline__ void critic_block(const Dev &d, const float *__restri
     }
 }
 
-template <int NTH>
+template <int NTH, bool XW = false>
 __device__ __forceinline__ void policy_block(const Dev &d, const StepArg &sa, int rb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int B = d.B, A = d.A;
@@ -118,10 +153,10 @@ __device__ __forceinline__ void policy_block(const Dev &d, const StepArg &sa, in
     const int gi = (row0 + row) * 16 + a;
     const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
     float act = 0.f, dap0 = 0.f, dap1 = 0.f, lsv = 0.f, epv = 0.f, okv = 0.f;
-    const float qa = d.qpart[(size_t)2 * B + row0 + row], qb = d.qpart[(size_t)3 * B + row0 + row];
+    const float qa = xload<XW>(d.qpart + (size_t)2 * B + row0 + row), qb = xload<XW>(d.qpart + (size_t)3 * B + row0 + row);
     if (a < A) {
         act = d.anew[gi];
-        dap0 = d.dapart[gi]; dap1 = d.dapart[(size_t)B * 16 + gi];
+        dap0 = xload<XW>(d.dapart + gi); dap1 = xload<XW>(d.dapart + (size_t)B * 16 + gi);
         lsv = d.ls[gi]; epv = d.epsv[gi]; okv = d.lsok[gi];
     }
     SB();
@@ -141,7 +176,8 @@ __device__ __forceinline__ void policy_block(const Dev &d, const StepArg &sa, in
     for (int t = 0; t < CT; ++t) h1v[t] = ld4(d.PH1T + frag_off(n0 + 16 * t + c, row0 + 4 * g, B));
     SB();
     for (int e = threadIdx.x; e < RB * 64; e += 512) XH[e] = 0.f;
-    const float alpha = alpha_step(d.ctl, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+    const float alpha = XW ? alpha_step_xw(d.ctl, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha
+                           : alpha_step(d.ctl, d.part_logpi, d.NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
     lds_barrier();
     USE_FROM_HERE(act); USE_FROM_HERE(lsv); USE_FROM_HERE(epv); USE_FROM_HERE(okv);
     USE_FROM_HERE(dap0); USE_FROM_HERE(dap1);
@@ -209,6 +245,6 @@ __global__ __launch_bounds__(512) void k_bwd8(Dev d, const float *__restrict__ S
     if (compact) { cls = (blockIdx.x & 7) >> 1; b = 2 * (blockIdx.x >> 3) + (blockIdx.x & 1); }
     else { cls = blockIdx.x % 3; b = blockIdx.x / 3; }
     if (cls > 2) return;
-    if (cls < 2) bwd8::critic_block(d, S, SL, sa, cls, b);
+    if (cls < 2) bwd8::critic_block<false>(d, S, SL, sa, cls, b);
     else bwd8::policy_block<NTH>(d, sa, b);
 }

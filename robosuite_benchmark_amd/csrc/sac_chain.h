@@ -432,13 +432,14 @@ __device__ __forceinline__ void to_lds(const f32x4 (&acc)[CT], const float (&bv)
 }
 
 // (the first four waves: thread = (row, 16 lanes), as in k_chain)
+template <bool SC1 = false>        // SC1: another workgroup of this launch reads the values (k_chain8<.., BWD>)
 __device__ __forceinline__ void q_value(const float (&w3)[16], const float *XS, float *out) {
     const int row = (threadIdx.x & 255) >> 4, a = threadIdx.x & 15;
     float s = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) s += XS[lds_off(row, a + 16 * u, H)] * w3[u];
     s = group16_sum(s);
-    if (a == 0 && threadIdx.x < 256) out[row] = s;
+    if (a == 0 && threadIdx.x < 256) { if constexpr (SC1) st_sc1(out + row, s); else out[row] = s; }
 }
 __device__ __forceinline__ void load_w3(const float *P, const Layer &L2, float (&w3)[16]) {
     const int a = threadIdx.x & 15;
@@ -447,7 +448,7 @@ __device__ __forceinline__ void load_w3(const float *P, const Layer &L2, float (
 }
 
 // split-K epilogue of a product that the FIRST FOUR waves computed (splitk_reduce's sum, in its order)
-template <int NTT>
+template <int NTT, bool SC1 = false>
 __device__ __forceinline__ void reduce4(const f32x4 (&acc)[NTT], float *red, float *out, int ldo) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave < 4) {
@@ -460,7 +461,8 @@ __device__ __forceinline__ void reduce4(const f32x4 (&acc)[NTT], float *red, flo
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[((w * NTT + t) * 64 + l) * 4 + i];
-        out[(4 * (l >> 4) + i) * ldo + 16 * t + (l & 15)] = s;
+        float *o = out + (4 * (l >> 4) + i) * ldo + 16 * t + (l & 15);
+        if constexpr (SC1) st_sc1(o, s); else *o = s;
     }
     lds_barrier();
 }
@@ -496,9 +498,19 @@ __device__ __forceinline__ void q_pass(const Dev &d, const float *PQ, Ring &A_, 
 // paid in the general step's matrix-product kernel, sac_general.h).  Every tile's MFMA sequence is k_chain's: the results
 // are k_chain's bit for bit; the per-row sections (row staging, head, q values) and the two split-K products (head, action
 // gradient: four partials, summed in k_chain's order) run on the first four waves.
+// BWD (round 3's last hours): the BACKWARD launch inside this one.  The only all-to-all seam between the forward and the
+// backward pass is the entropy coefficient -- NB row-block sums of log pi -- and with 4 * NB <= CUs every workgroup of the launch
+// is resident, so the seam can be an in-launch hand-off (sac_fused.h's protocol: write-through stores, one relaxed agent-scope
+// counter per producer group, a 50-ms give-up that makes the weight-gradient launch apply nothing and the host fall back to
+// k_chain8 + k_bwd8): every backward block needs the target values, i.e. starts behind item N's forward, the longest -- so the
+// three blocks of a row-block go to three different items, each behind its own hand-off: item C (the shortest) publishes its
+// Q2(s, a) pass and runs Q1's critic block once item N has published T1 / T2 / log pi'; item N runs Q2's critic block on item
+// C's activations; item P0 runs the policy block once P1 has published Q2(s, a_new) and dQ2/da; all behind the log-pi sums of
+// every P0 item.  (With both critic blocks in item C the launch took 45.7 us: they run one after the other there.)  Same
+// blocks, same arithmetic as k_bwd8: bit-identical to k_chain8 + k_bwd8.
 // grid: 4 * NB workgroups (NB even).  b % 8 -> item (two slots each: blocks that share an XCD under round-robin placement
 // run the same item, i.e. stream the same networks), row-block 2 (b / 8) + (b & 1).
-template <int NTH, bool WIDE>
+template <int NTH, bool WIDE, bool BWD = false>
 __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     kernarg_prefetch<sizeof(Dev) + 8 + sizeof(SlotLayout) + sizeof(StepArg)>();
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -511,6 +523,12 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
     float *HD = red + 4 * NTH * 256;     // [16][32] head pre-activations of the row-block
     const int xr = blockIdx.x & 7, item = xr >> 1, rb = 2 * (blockIdx.x >> 3) + (xr & 1);
     if (rb >= d.NB) return;
+    // hand-off counters (BWD): tq[rb] <- item N, ac[rb] <- item P1, lp <- every P0 item (units of the launch number)
+    unsigned *cnt_qa = d.cnt + (size_t)2 * d.NB * CNT_STRIDE, *cnt_tq = d.cnt + (size_t)3 * d.NB * CNT_STRIDE,
+             *cnt_ac = d.cnt + (size_t)4 * d.NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)5 * d.NB * CNT_STRIDE;
+    __shared__ int s_ok;
+    // test hook (the give-up path must work on hardware): on the launch the host marks, item N of row-block 0 leaves without publishing
+    if (BWD && (sa.pad2 & 1u) && blockIdx.x == 4) return;
     const int row0 = rb * RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const bool lo = threadIdx.x < 256;                        // the waves that run the per-row sections
@@ -543,10 +561,20 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
         chain8::q_value(w3, XS, d.qpart + row0);
         lds_barrier();                   // (X1 / XS are reused by the second twin)
         chain8::q_pass<6, WIDE>(d, d.P[2], RA, RBm, X0, KLQ, X1, XS, keep1, keep2, [&] { chain8::load_w3(d.P[2], d.LQ[2], w3); });
-        store_features<chain8::CT>(keep1, chain8::CF * wave, 16, d.QH1T + (size_t)H * B, B, row0);
-        store_features<chain8::CT>(keep2, chain8::CF * wave, 16, d.QH2T + (size_t)H * B, B, row0);
-        chain8::q_value(w3, XS, d.qpart + (size_t)B + row0);
+        // (BWD: the second twin's activations and q values are item N's operands -- it runs that twin's critic backward)
+        store_features<chain8::CT, BWD>(keep1, chain8::CF * wave, 16, d.QH1T + (size_t)H * B, B, row0);
+        store_features<chain8::CT, BWD>(keep2, chain8::CF * wave, 16, d.QH2T + (size_t)H * B, B, row0);
+        chain8::q_value<BWD>(w3, XS, d.qpart + (size_t)B + row0);
         STAMP(0, 12);
+        if constexpr (BWD) {
+            handoff_publish(cnt_qa + (size_t)rb * CNT_STRIDE);
+            // the target values of this row-block and the log-pi sums of all: then Q1's critic backward block
+            handoff_wait_multi<16>(2, cnt_tq + (size_t)rb * CNT_STRIDE, sa.seq, cnt_lp, (unsigned)d.NB * sa.seq, cnt_lp, (unsigned)d.NB * sa.seq,
+                               d.abort_flag, &s_ok);
+            lds_barrier();
+            if (!s_ok) return;
+            bwd8::critic_block<true>(d, S, SL, sa, 0, rb);
+        }
         return;
     }
 
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
         if (a == 0) { d.logpi[grow] = lsum; red[row] = (grow < d.Bt) ? lsum : 0.f; }
     } else if (item == 2 && lo) {
         d.a2[grow * 16 + a] = act;
-        if (a == 0) d.logpi2[grow] = lsum;
+        if (a == 0) { if constexpr (BWD) st_sc1(d.logpi2 + grow, lsum); else d.logpi2[grow] = lsum; }
     }
     // the Q nets' input: [obs | 0 | action | 0]: the observation columns are in place, the action chunk is written now
     // (columns O .. KP-1 are zero from the commit; the policy's GEMM never read beyond KP)
@@ -642,7 +670,13 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
     if (own && threadIdx.x == 0) {       // this row-block's sum(log pi), fixed order
         float s = 0.f;
         for (int i = 0; i < RB; ++i) s += red[i];
-        d.part_logpi[rb] = s;
+        if constexpr (BWD) {
+            st_sc1(d.part_logpi + rb, s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(cnt_lp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            d.part_logpi[rb] = s;
+        }
     }
 
     if (item == 2) {
@@ -652,11 +686,20 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
             RA.fill(d.KQ >> 4);
             chain8::load_w3(d.P[3], d.LQ[2], w3);
         });
-        chain8::q_value(w3, XS, d.qpart + (size_t)4 * B + row0);
+        chain8::q_value<BWD>(w3, XS, d.qpart + (size_t)4 * B + row0);
         lds_barrier();
         chain8::q_pass<8, WIDE>(d, d.P[4], RA, RBm, X0, KLQ, X1, XS, keep1, keep2, [&] { chain8::load_w3(d.P[4], d.LQ[2], w3); });
-        chain8::q_value(w3, XS, d.qpart + (size_t)5 * B + row0);
+        chain8::q_value<BWD>(w3, XS, d.qpart + (size_t)5 * B + row0);
         STAMP(0, 12);
+        if constexpr (BWD) {
+            handoff_publish(cnt_tq + (size_t)rb * CNT_STRIDE);
+            // item C's Q2(s, a) pass of this row-block (long out) and the log-pi sums of all: then Q2's critic backward block
+            handoff_wait_multi<16>(2, cnt_qa + (size_t)rb * CNT_STRIDE, sa.seq, cnt_lp, (unsigned)d.NB * sa.seq, cnt_lp, (unsigned)d.NB * sa.seq,
+                               d.abort_flag, &s_ok);
+            lds_barrier();
+            if (!s_ok) return;
+            bwd8::critic_block<true>(d, S, SL, sa, 1, rb);
+        }
         return;
     }
 
@@ -670,7 +713,7 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
     RBm.init(PT + d.LQ[1].offWt, H, chain8::CF * wave, 16);
     RBm.fill(H >> 4);
     SB();
-    chain8::q_value(w3, XS, d.qpart + (size_t)(2 + qi) * B + row0);
+    chain8::q_value<BWD>(w3, XS, d.qpart + (size_t)(2 + qi) * B + row0);
     // dq/dh2 = w3 * relu'(h2), in place (own elements)
     if (lo) {
 #pragma unroll
@@ -698,8 +741,18 @@ __global__ __launch_bounds__(512) void k_chain8(Dev d, const float *__restrict__
     {   // dq/da = dq/dh1 . W1[:, action columns]  (contraction split over the waves)
         f32x4 acc[1] = {};
         if (wave < 4) gemm_ring(ra, X1, H, 4, acc, 4 * wave);
-        chain8::reduce4<1>(acc, red, d.dapart + ((size_t)qi * B + row0) * 16, 16);
+        chain8::reduce4<1, BWD>(acc, red, d.dapart + ((size_t)qi * B + row0) * 16, 16);
     }
     STAMP(0, 12);
+    if constexpr (BWD) {
+        if (qi == 1) { handoff_publish(cnt_ac + (size_t)rb * CNT_STRIDE); return; }
+        // P0: the other twin's q_new and action gradient, the log-pi sums of all row-blocks: then the policy backward block
+        handoff_wait_multi<16>(2, cnt_ac + (size_t)rb * CNT_STRIDE, sa.seq, cnt_lp, (unsigned)d.NB * sa.seq, cnt_lp, (unsigned)d.NB * sa.seq,
+                           d.abort_flag, &s_ok);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (!s_ok) return;
+        bwd8::policy_block<NTH, true>(d, sa, rb);
+    }
 }
 #undef CHAIN8_GEMM16

@@ -43,6 +43,9 @@ constexpr unsigned long long HANDOFF_TIMEOUT_TICKS = 5000000ull;   // s_memrealt
 constexpr int FUSED_RED = 2048;                                 // floats of split-K scratch
 
 // one lane: wait until *cnt has reached target (wrap-safe); false = abort (ours or somebody else's)
+// (SLEEP: s_sleep units of 64 cycles between polls -- 1 for the short waits of k_abc; the long waits of k_chain8<.., BWD>, where
+//  half the chip polls for microseconds, back off further)
+template <int SLEEP = 1>
 __device__ __forceinline__ int handoff_wait(const unsigned *cnt, unsigned target, unsigned *abort_flag) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
@@ -53,12 +56,13 @@ __device__ __forceinline__ int handoff_wait(const unsigned *cnt, unsigned target
             __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return 0;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(SLEEP);
     }
 }
 
 // Wave 0: lanes 0 .. n-1 wait for one counter each -- ONE memory round trip per poll iteration for all of them
 // (three waits one after the other cost three round trips: +0.8 us measured).  *s_ok = 1 iff every counter got there.
+template <int SLEEP = 1>
 __device__ __forceinline__ void handoff_wait_multi(int n, const unsigned *c0, unsigned t0, const unsigned *c1, unsigned t1,
                                                    const unsigned *c2, unsigned t2, unsigned *abort_flag, int *s_ok) {
     if (threadIdx.x < 64) {
@@ -66,7 +70,7 @@ __device__ __forceinline__ void handoff_wait_multi(int n, const unsigned *c0, un
         const unsigned *c = (l == 0) ? c0 : ((l == 1) ? c1 : c2);
         const unsigned t = (l == 0) ? t0 : ((l == 1) ? t1 : t2);
         int ok = 1;
-        if (l < n) ok = handoff_wait(c, t, abort_flag);
+        if (l < n) ok = handoff_wait<SLEEP>(c, t, abort_flag);
         const unsigned long long all = __ballot(ok != 0);
         if (l == 0) *s_ok = (all == ~0ull) ? 1 : 0;
     }

@@ -1767,6 +1767,8 @@ struct sac_trainer {
     int fallbacks = 0;                                // times the fused step gave up (at most once: the fall-back is for good)
     void (*abc)(Dev, const float *, SlotLayout, StepArg) = nullptr;
     size_t lds_abc = 0;
+    int abc_grid = 0, abc_threads = 256;              // the fused launch's shape (k_abc: 16 NB x 256; k_chain8<.., BWD>: 4 NB x 512)
+    bool chain_bwd = false;                           // batch 1024: the fused launch is k_chain8 with the backward blocks inside
     unsigned *d_sync = nullptr; size_t sync_bytes = 0;   // counters (one per 128-B line) + abort word
     void (*fwd_a)(Dev, const float *, SlotLayout, int) = nullptr;
     void (*fwd_b)(Dev, const float *, SlotLayout, StepArg) = nullptr;
@@ -1894,7 +1896,7 @@ int launch_fused_abc(sac_trainer *t, const float *S, const SlotLayout &SL, StepA
     std::lock_guard<std::mutex> lk(G.mu);
     const bool gate = G.live > 1 && !t->gate_exempt;
     if (gate && G.last && G.last != s) SAC_HIP(hipStreamWaitEvent(s, G.ev, 0));
-    hipLaunchKernelGGL(t->abc, dim3(16 * t->NB), dim3(256), t->lds_abc, s, t->dev, S, SL, sa);
+    hipLaunchKernelGGL(t->abc, dim3(t->abc_grid), dim3(t->abc_threads), t->lds_abc, s, t->dev, S, SL, sa);
     if (gate) { SAC_HIP(hipEventRecord(G.ev, s)); G.last = s; }
     return 0;
 }
@@ -2376,6 +2378,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
         if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
         if (td3) t->abc = wide ? &k_abc<1, true, M_TD3_CRITIC> : &k_abc<1, false, M_TD3_CRITIC>;
         else t->abc = (nth == 1) ? (wide ? &k_abc<1, true> : &k_abc<1, false>) : (wide ? &k_abc<2, true> : &k_abc<2, false>);
+        t->abc_grid = 16 * t->NB; t->abc_threads = 256;
         if (t->fused) {
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->abc), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)t->lds_abc));
@@ -2410,6 +2413,31 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
             const char *eb = getenv("SAC_BWD8");
             t->bwd8 = !td3 && t->SP == 1 && !(eb && atoi(eb) == 0);
             if (t->bwd8) t->bwd = (nth == 1) ? &k_bwd8<1> : &k_bwd8<2>;
+        }
+        {   // one round of workgroups (batch 1024): the backward blocks inside the forward launch behind in-launch hand-offs
+            // (k_chain8<.., BWD>, sac_chain.h) -- a fused step like k_abc's: same give-up protocol, same fall-back (to k_chain8 + k_bwd8)
+            // Where it pays (A/B on one box, 2 x 2000 steps): exactly one workgroup per CU and narrow first layers -- Door 46/7
+            // batch 1024 19 290 -> 19 860 steps/s (the launch 33.6 us for 22.3 + 10.6 + a boundary); TwoArmHandoff 86/14 batch 1024
+            // -3.5 %, batch 992 -3 %, batch 800 -8 % (fewer workgroups than CUs: the separate backward launch was spreading its
+            // 192 blocks over idle CUs).  SAC_CHAIN_BWD=1 / 0 forces it (any batch whose workgroups are all resident) / off.
+            const char *ecb = getenv("SAC_CHAIN_BWD");
+            const bool pays_b = 4 * t->NB == cus && t->KQ <= 64;
+            t->chain_bwd = t->chain && t->chain8 && t->bwd8 && 4 * t->NB <= cus && (ecb ? atoi(ecb) == 1 : pays_b);
+            if (t->chain_bwd) {
+                const bool wide4 = t->KQ > 64;
+                t->abc = (nth == 1) ? (wide4 ? &k_chain8<1, true, true> : &k_chain8<1, false, true>)
+                                    : (wide4 ? &k_chain8<2, true, true> : &k_chain8<2, false, true>);
+                t->lds_abc = t->lds_chain > sizeof(float) * (size_t)(RB * 64 + RB * H) ? t->lds_chain : sizeof(float) * (size_t)(RB * 64 + RB * H);
+                t->abc_grid = 4 * t->NB; t->abc_threads = 512;
+                t->fused = true;
+                if (const char *ts = getenv("SAC_FUSED_TEST_STALL")) t->test_stall_at = (unsigned)atoi(ts);
+                SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->abc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->lds_abc));
+                set_abort_ptrs(t, d.abort_flag);
+                FusedGate &G = g_gate[t->device & 63];
+                std::lock_guard<std::mutex> lk(G.mu);
+                if (!G.ev) SAC_HIP(hipEventCreateWithFlags(&G.ev, hipEventDisableTiming));
+                G.live += 1;
+            }
         }
         if (t->chain && t->lds_chain > 64 * 1024)
             SAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(t->chaink), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3114,7 +3142,7 @@ int sac_trainer_set_xcd_mask(sac_trainer_t *t, unsigned xcd_mask) {
         FusedGate &G = g_gate[t->device & 63];
         std::lock_guard<std::mutex> lk(G.mu);
         if (!t->gate_exempt) G.live -= 1;
-        if (16 * t->NB <= mine && (xcd_mask & 0xffu) != 0xffu) {
+        if (t->abc_grid <= mine && (xcd_mask & 0xffu) != 0xffu) {
             t->gate_exempt = true;
         } else if ((xcd_mask & 0xffu) == 0xffu) {
             t->gate_exempt = false;
@@ -3134,7 +3162,7 @@ int sac_trainer_set_xcd(sac_trainer_t *t, int xcd) {
 
 // 1 while this trainer runs the fused two-launch step (k_abc + k_dw_adam), 0 for the four-launch step
 int sac_trainer_is_fused(const sac_trainer_t *t) { return (t && t->fused) ? 1 : 0; }
-int sac_trainer_step_kind(const sac_trainer_t *t) { return !t ? -1 : (t->gen ? 3 : (t->fused ? 1 : (t->chain ? 2 : 0))); }
+int sac_trainer_step_kind(const sac_trainer_t *t) { return !t ? -1 : (t->gen ? 3 : (t->fused ? (t->chain_bwd ? 4 : 1) : (t->chain ? 2 : 0))); }
 
 int sac_last_loop_ms(sac_trainer_t *t, float *total_ms, float *sample_ms, float *gather_ms, float *steps_ms) {
     SAC_REQUIRE(t, "null trainer");

@@ -219,11 +219,14 @@ class SACTrainer:
             names[2], names[3], names[4] = "k_fwd_abc", "fused_b", "fused_c"
         elif mode == 2:              # column split 1: k_chain = launches A + B in one (the next slot reads 0)
             names[2], names[3] = "k_chain", "chain_b"
+        elif mode == 4:              # ... with the backward blocks inside too (the next two slots read 0)
+            names[2], names[3], names[4] = "k_chain_bwd", "chain_b", "chain_c"
         return OrderedDict(zip(names, [float(x) for x in ms]))
 
     def fused_mode(self):
         """0: four launches per step; 1: the fused step, k_abc + k_dw_adam; 2: k_chain + k_bwd + k_dw_adam (batch >= 1024);
-        3: the general step (hidden_sizes beyond two layers of at most 256 units)."""
+        3: the general step (hidden_sizes beyond two layers of at most 256 units); 4: k_chain8 with the backward blocks inside
+        + k_dw_adam (batch 1024, SAC_CHAIN_BWD=1)."""
         return int(self._lib.sac_trainer_step_kind(self._h)) if self._h is not None else 0
 
     def is_fused(self):
