@@ -28,7 +28,9 @@
 // s_sleep), workgroup barrier, then loads.  Counters are monotonic (targets are multiples of the launch number:
 // no reset, no ABA).  Every handed-off datum lives in 128-B lines that ONE producer block writes and nobody reads
 // before the counter says so, so neither a CU's L1 nor an XCD's L2 can hold a stale copy of them (both are
-// invalidated at dispatch); 4-byte consumer loads are sc1 (L1-bypassing) on top of that.
+// invalidated at dispatch); 4-byte consumer loads are sc1 (L1-bypassing) on top of that.  The one single-word hand-off -- a
+// row-block's sum of log pi, 16 words for the entropy coefficient of every phase C -- travels as {launch number, value} in ONE
+// 8-byte store instead (tagged_publish / tagged_wait: no drain, no counter; the poll returns the value).
 //
 // Residency: the 16*NB blocks (<= 256, ~106 KB of LDS each: one per CU) must all be resident -- true when the launch
 // has the chip to itself.  Nothing spins forever: a wait gives up after 50 ms (s_memrealtime), raises the sticky abort
@@ -76,21 +78,63 @@ __device__ __forceinline__ void handoff_wait_multi(int n, const unsigned *c0, un
     }
 }
 
+// A single value handed over as ONE 8-byte word {launch number, value}: the datum is its own signal.  The producer neither drains
+// its stores nor touches a counter (a wave that waits for its write-through stores to be acknowledged is ~0.4 us late at the
+// workgroup's next barrier -- measured on the block that publishes a row-block's sum of log pi, which sits on the step's
+// critical path); the consumer's poll returns the value with the tag.
+__device__ __forceinline__ void tagged_publish(unsigned long long *p, float v, unsigned seq) {
+    const unsigned long long w = ((unsigned long long)seq << 32) | (unsigned long long)__builtin_bit_cast(unsigned, v);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int SLEEP = 1>
+__device__ __forceinline__ int tagged_wait(const unsigned long long *p, unsigned seq, unsigned *abort_flag, float *v) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) == seq) { *v = __builtin_bit_cast(float, (unsigned)w); return 1; }
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return 0;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > HANDOFF_TIMEOUT_TICKS) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(SLEEP);
+    }
+}
+// handoff_wait_multi for up to two counters (lanes 0, 1) PLUS the NB tagged row-block sums of log pi (lanes 16 .. 16 + NB - 1; values to
+// s_lp[0 .. NB-1] in LDS): still one memory round trip per poll iteration for all of them
+__device__ __forceinline__ void handoff_wait_multi_lp(int n, const unsigned *c0, unsigned t0, const unsigned *c1, unsigned t1,
+                                                      const unsigned long long *lp_tag, int NB, unsigned seq, unsigned *abort_flag,
+                                                      int *s_ok, float *s_lp) {
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        int ok = 1;
+        if (l < n) ok = handoff_wait(l == 0 ? c0 : c1, l == 0 ? t0 : t1, abort_flag);
+        else if (l >= 16 && l < 16 + NB) {
+            float v = 0.f;
+            ok = tagged_wait(lp_tag + (l - 16), seq, abort_flag, &v);
+            s_lp[l - 16] = v;
+        }
+        const unsigned long long all = __ballot(ok != 0);
+        if (l == 0) *s_ok = (all == ~0ull) ? 1 : 0;
+    }
+}
+
 // every wave: its stores have left; then ONE lane signals for the whole workgroup
 __device__ __forceinline__ void handoff_publish(unsigned *cnt) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// alpha_step with the row-block sums read by vector sc1 loads (they were written earlier in THIS launch); the sum runs
-// in the same order as alpha_step's, so launch D's diagnostics block computes bit-identical state from the same words
+// alpha_step with the row-block sums taken from LDS (handoff_wait_multi_lp left them there: they were published earlier in THIS
+// launch); the sum runs in the same order as alpha_step's, so launch D's diagnostics block computes bit-identical state from
+// the same words (the float copies in d.part_logpi)
 __device__ __forceinline__ AlphaStep alpha_step_v(const Ctl *ctl, const float *part_logpi, int NB, int B, float target_entropy,
                                                   float lr, int auto_alpha, double bc1, double bc2s) {
     AlphaStep r;
     const float la = sload(&ctl->log_alpha), m0 = sload(&ctl->a_m), v0 = sload(&ctl->a_v);
     if (!auto_alpha) { r.alpha = 1.0f; r.alpha_loss = 0.0f; r.log_alpha = la; r.m = m0; r.v = v0; return r; }
     const int lane = threadIdx.x & 63;
-    const float mine = ld_sc1(part_logpi + (lane < NB ? lane : 0));
+    const float mine = part_logpi[lane < NB ? lane : 0];      // (LDS)
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -146,6 +190,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_ok;
     __shared__ float s_dq[RB];
+    __shared__ float s_lp[16];          // the row-block sums of log pi (phase C's entropy coefficient)
     const int B = d.B, O = d.O, A = d.A, NB = d.NB;
     const int KLQ = (d.KQ + 63) & ~63;
     float *X0 = lds;                     // [16][KLQ]  input rows (phase A), cat(obs, action) (phase B)
@@ -168,10 +213,11 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     const int row = threadIdx.x >> 4, a = threadIdx.x & 15, grow = row0 + row;
     const int n0 = SW * part + 16 * wave;                     // this wave's tile of the split layers
     // counters (one per 128-B line): head[side][rb] (policy chain, phase A), qa[rb] (critic chain, phase A), tq[rb] (policy
-    // chains, phase B), ac[rb] (critic chain, phase B incl. the actor tail), lp (row-block sums of log pi)
+    // chains, phase B), ac[rb] (critic chain, phase B incl. the actor tail); the NB row-block sums of log pi need none: tagged words
     unsigned *cnt_head = d.cnt, *cnt_qa = d.cnt + (size_t)2 * NB * CNT_STRIDE, *cnt_tq = d.cnt + (size_t)3 * NB * CNT_STRIDE,
-             *cnt_ac = d.cnt + (size_t)4 * NB * CNT_STRIDE, *cnt_lp = d.cnt + (size_t)5 * NB * CNT_STRIDE;
+             *cnt_ac = d.cnt + (size_t)4 * NB * CNT_STRIDE;
     unsigned *cnt_zx = d.cnt + (size_t)(5 * NB + 2) * CNT_STRIDE;   // [6 chains][NB]: the exchange of the split first layers (WIDE)
+    unsigned long long *lp_tag = reinterpret_cast<unsigned long long *>(d.cnt + (size_t)(11 * NB + 2) * CNT_STRIDE);   // [NB] {launch, sum of log pi}
     const unsigned seq = sa.seq;
     const bool own_s = isq && net == 0 && part == 0, own_n = !isq && net == 0 && part == 0;
     // test hook (tests/test_gpu_fused_step.py: the give-up path must work on hardware): on the launch the host marks,
@@ -464,7 +510,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
             }
             d.anew[grow * 16 + a] = act;                     // (0 beyond A)
             if (a == 0) d.logpi[grow] = lsum;
-            if (threadIdx.x == 0) st_sc1(d.part_logpi + rb, lsum_blk);
+            if (threadIdx.x == 0) { d.part_logpi[rb] = lsum_blk; tagged_publish(lp_tag + rb, lsum_blk, seq); }   // (float copy: launch D)
         } else if (own_n) {
             d.a2[grow * 16 + a] = act;
             if (MODE == M_SAC && a == 0) { d.logpi2[grow] = lsum; st_sc1(d.logpi2p + rb * 32 + row, lsum); }
@@ -480,10 +526,6 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         if (a == 0) st_sc1(d.qpart2 + ((size_t)(pass * NB + rb) * SP + part) * 32 + row, s);
     }
     STAMP(0, 5);
-    if (own_s && threadIdx.x == 0) {        // the row-block sum of log pi is out: the entropy coefficient of phase C needs all NB of them
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(cnt_lp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     // critic chain: the transposed W2 slice of the critic backward (phase C) is requested HERE, in front of the actor
     // tail -- it depends on no hand-off, and its first eight k-chunks land while the tail runs
     if (isq) {
@@ -542,8 +584,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const int k = threadIdx.x;
         // the three counters in ONE round trip, with nothing of this block in flight; the target partials have usually been
         // out for a microsecond by now (the policy chains have no actor tail)
-        handoff_wait_multi((MODE == M_SAC) ? 3 : 2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp,
-                           (unsigned)NB * seq, d.abort_flag, &s_ok);
+        handoff_wait_multi_lp(2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, lp_tag,
+                              (MODE == M_SAC) ? NB : 0, seq, d.abort_flag, &s_ok, s_lp);
         lds_barrier();
         if (!s_ok) return;
         STAMP(0, 8);
@@ -570,7 +612,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         h1v[0] = ld4(h1T + frag_off(n0 + c, row0 + 4 * g, B));
         float alpha = 0.f;                                                   // (TD3: no entropy term in the target)
         if constexpr (MODE == M_SAC)
-            alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+            alpha = alpha_step_v(d.ctl, s_lp, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         float va = 0.f, vb = 0.f, vq = 0.f, yv = 0.f, dq = 0.f;
         if (threadIdx.x < RB) {
             va = qa[0]; vb = qb[0]; vq = qq[0];
@@ -638,8 +680,8 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         const float b3a = sload(d.P[1] + oB3), b3b = sload(d.P[2] + oB3);
         SB();
         for (int e = threadIdx.x; e < RB * 64; e += 256) XH[e] = 0.f;
-        handoff_wait_multi(2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_lp, (unsigned)NB * seq, cnt_lp, (unsigned)NB * seq,
-                           d.abort_flag, &s_ok);               // the policy chains' phases A + B (pi(s)'s activations), the log-pi sums
+        handoff_wait_multi_lp(1, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, nullptr, 0u, lp_tag, NB, seq,
+                              d.abort_flag, &s_ok, s_lp);      // the policy chains' phases A + B (pi(s)'s activations), the log-pi sums
         lds_barrier();
         if (!s_ok) return;
         f32x4 h2v[4];
@@ -647,7 +689,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         for (int t = 0; t < 4; ++t) h2v[t] = ld4(d.PH2T + frag_off(64 * wave + 16 * t + c, row0 + 4 * g, B));
         f32x4 h1v[1];
         h1v[0] = ld4(d.PH1T + frag_off(nt + c, row0 + 4 * g, B));
-        const float alpha = alpha_step_v(d.ctl, d.part_logpi, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
+        const float alpha = alpha_step_v(d.ctl, s_lp, NB, d.Bt, d.target_entropy, d.alpha_lr, d.auto_alpha, sa.bc1, sa.bc2s).alpha;
         if (threadIdx.x == 0) s_ok = handoff_wait(cnt_ac + (size_t)rb * CNT_STRIDE, 8u * seq, d.abort_flag);   // the eight actor tails
         lds_barrier();
         if (!s_ok) return;

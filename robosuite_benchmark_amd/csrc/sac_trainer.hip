@@ -2241,7 +2241,7 @@ static int trainer_build(sac_trainer *t, const sac_config_t *cfg, const td3_conf
     if (alloc_zero(&t->d_diag, (long long)SAC_DIAG_N * (2 + DIAG_TRACE_CAP), s)) return -1;
     arena.reserve(reinterpret_cast<void **>(&t->d_ctl), sizeof(Ctl));
     // head[2][NB], qa / tq / ac [NB], log-pi, abort; then zx[6][NB] (the exchange of the split first layers)
-    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (5 * t->NB + 2 + 6 * t->NB);
+    t->sync_bytes = sizeof(unsigned) * (size_t)CNT_STRIDE * (5 * t->NB + 2 + 6 * t->NB + 1);   // (+1: k_abc's tagged sums of log pi)
     arena.reserve(reinterpret_cast<void **>(&t->d_sync), t->sync_bytes);
     arena.reserve(reinterpret_cast<void **>(&t->d_dwl), sizeof(DwLayer) * NDW * 3);
     g_arena = nullptr;

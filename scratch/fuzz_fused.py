@@ -40,7 +40,9 @@ for c in range(cases):
             for s_ in range(3):
                 nb, eps = batch_and_noise(B, O, A, seed=1000 * c + s_, term_frac=0.1)
                 want = oracle.step(nb["observations"], nb["actions"], nb["rewards"], nb["terminals"], nb["next_observations"], *eps)
-                check_diag(hip.train(nb, eps=eps), want, tol=2e-4 if s_ else 2 * TOL)
+                # (batches of many hundred rows reach |a| -> 1, where log(1 - a^2 + 1e-6) is ill-conditioned in fp32: 'Log Pis Min' of
+                #  1824 rows differs by 5e-5 relative between ANY two fp32 evaluation orders -- scratch/big_batches.py)
+                check_diag(hip.train(nb, eps=eps), want, tol=2e-4 if s_ else (1e-4 if B > 512 else 2 * TOL))
         k = hip.fused_mode()
         kinds[k] = kinds.get(k, 0) + 1
         print(f"case {c}: {'TD3' if td3 else 'SAC'} hidden {hp}/{hq} obs {O} act {A} batch {B} step kind {k}: ok", flush=True)

@@ -67,3 +67,13 @@ for st_i, nm in ((1, "A done"), (6, "B done"), (9, "end")):
                 g[f(b)].append((w[b, st_i] - t0) / 100.0)
         print(f"critic chain {nm:7s} by {key:5s}:", " ".join(f"{k}:{np.median(v):.2f}" for k, v in sorted(g.items())))
 
+# the critic chain by (twin, column part): which block of a row-block's eight is the straggler, and from which stamp on
+g = collections.defaultdict(list)
+for b in blocks:
+    xr = (b & 7) ^ XOR
+    if xr < 4:
+        g[((xr >> 1) & 1, (2 * (b >> 3) + (b & 1)) & 3)].append((w[b, :10] - t0) / 100.0)
+print("critic chain by (twin, part): " + "  ".join(names[i] for i in (1, 3, 4, 5, 6, 7, 8, 9)))
+for k, v in sorted(g.items()):
+    v = np.median(np.array(v), axis=0)
+    print("   ", k, " ".join(f"{v[i]:6.2f}" for i in (1, 3, 4, 5, 6, 7, 8, 9)))
