@@ -102,21 +102,37 @@ __device__ __forceinline__ int tagged_wait(const unsigned long long *p, unsigned
 }
 // handoff_wait_multi for up to two counters (lanes 0, 1) PLUS the NB tagged row-block sums of log pi (lanes 16 .. 16 + NB - 1; values to
 // s_lp[0 .. NB-1] in LDS): still one memory round trip per poll iteration for all of them
+// (peek: what multi_lp_peek loaded for this lane some time ago -- an early look that usually finds everything there, so that the
+//  wait costs no memory round trip: 0.6-0.8 us at the start of the critic chain's phase C, whose conditions have been true for a
+//  microsecond by then; 0 = no early look)
 __device__ __forceinline__ void handoff_wait_multi_lp(int n, const unsigned *c0, unsigned t0, const unsigned *c1, unsigned t1,
                                                       const unsigned long long *lp_tag, int NB, unsigned seq, unsigned *abort_flag,
-                                                      int *s_ok, float *s_lp) {
+                                                      int *s_ok, float *s_lp, unsigned long long peek = 0ull) {
     if (threadIdx.x < 64) {
         const int l = threadIdx.x;
         int ok = 1;
-        if (l < n) ok = handoff_wait(l == 0 ? c0 : c1, l == 0 ? t0 : t1, abort_flag);
-        else if (l >= 16 && l < 16 + NB) {
-            float v = 0.f;
-            ok = tagged_wait(lp_tag + (l - 16), seq, abort_flag, &v);
+        if (l < n) {
+            const unsigned t = l == 0 ? t0 : t1;
+            if ((int)((unsigned)peek - t) < 0) ok = handoff_wait(l == 0 ? c0 : c1, t, abort_flag);
+        } else if (l >= 16 && l < 16 + NB) {
+            float v = __builtin_bit_cast(float, (unsigned)peek);
+            if ((unsigned)(peek >> 32) != seq) ok = tagged_wait(lp_tag + (l - 16), seq, abort_flag, &v);
             s_lp[l - 16] = v;
         }
         const unsigned long long all = __ballot(ok != 0);
         if (l == 0) *s_ok = (all == ~0ull) ? 1 : 0;
     }
+}
+// the early look for handoff_wait_multi_lp: wave 0's lanes load their counter / tagged word (issued in front of a publish of the
+// caller's own, whose drain covers the round trip)
+__device__ __forceinline__ unsigned long long multi_lp_peek(int n, const unsigned *c0, const unsigned *c1, const unsigned long long *lp_tag, int NB) {
+    unsigned long long w = 0ull;
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        if (l < n) w = __hip_atomic_load(l == 0 ? c0 : c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (l >= 16 && l < 16 + NB) w = __hip_atomic_load(lp_tag + (l - 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return w;
 }
 
 // every wave: its stores have left; then ONE lane signals for the whole workgroup
@@ -359,6 +375,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
     // phase B: requests that do not depend on the hand-off first, then the wait
     // =========================================================================================================
     WRing<1, 8> rc;                      // critic chain: the transposed W2 slice of the critic backward (phase C)
+    unsigned long long peek_c = 0ull;    // critic chain, wave 0: early look at phase C's counters / tagged words (multi_lp_peek)
     if (MODE == M_SAC || !isq) {         // (TD3 critic pass: the critic chain goes straight on to phase C)
     const int p4 = isq ? net : 2 + net;                       // Q1, Q2 on (s, a_new) | T1, T2 on (s', a')
     const int side = isq ? 0 : 1, pass = 2 + p4;
@@ -560,6 +577,9 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         }
     }
     STAMP(0, 6);
+    // (the critic chain's early look at what its phase C waits for -- the target partials, its siblings' phase A, the sums of
+    //  log pi: all out for a microsecond by now -- rides in the drain of this publish)
+    if (MODE == M_SAC && isq) peek_c = multi_lp_peek(2, cnt_tq + (size_t)rb * CNT_STRIDE, cnt_qa + (size_t)rb * CNT_STRIDE, lp_tag, NB);
     handoff_publish((isq ? cnt_ac : cnt_tq) + (size_t)rb * CNT_STRIDE);
     STAMP(0, 7);
     }   // phase B
@@ -585,7 +605,7 @@ __global__ __launch_bounds__(256) void k_abc(Dev d, const float *__restrict__ S,
         // the three counters in ONE round trip, with nothing of this block in flight; the target partials have usually been
         // out for a microsecond by now (the policy chains have no actor tail)
         handoff_wait_multi_lp(2, cnt_tq + (size_t)rb * CNT_STRIDE, 8u * seq, cnt_qa + (size_t)rb * CNT_STRIDE, 8u * seq, lp_tag,
-                              (MODE == M_SAC) ? NB : 0, seq, d.abort_flag, &s_ok, s_lp);
+                              (MODE == M_SAC) ? NB : 0, seq, d.abort_flag, &s_ok, s_lp, peek_c);
         lds_barrier();
         if (!s_ok) return;
         STAMP(0, 8);
