@@ -61,9 +61,9 @@ for env in ({}, {}, {"SAC_CHAIN": "0"}):
         os.environ.pop(k)
     _, last = tr.train_loop(buf, M, batch_size=1024)
     fin.append((tr.state_dict(), last, tr.fused_mode()))
-ok = fin[0][2] == 2 and fin[2][2] == 0 and same(fin[0][0], fin[1][0]) and np.array_equal(fin[0][1], fin[1][1])
+ok = fin[0][2] in (2, 4) and fin[2][2] == 0 and same(fin[0][0], fin[1][0]) and np.array_equal(fin[0][1], fin[1][1])
 rel = float(np.max(np.abs(fin[0][1][:28] - fin[2][1][:28]) / np.maximum(1.0, np.abs(fin[2][1][:28]))))
-print("k_chain: two runs of", M, "steps bitwise equal:", ok, "| vs four launches, max rel diff of the last diagnostics: %.2e" % rel,
+print("chained launch (step kind %d): two runs of" % fin[0][2], M, "steps bitwise equal:", ok, "| vs four launches, max rel diff of the last diagnostics: %.2e" % rel,
       "%.1f s" % (time.time() - t0), flush=True)
 assert ok and np.isfinite(fin[0][1][:28]).all() and rel < 0.5      # (chaotic divergence over thousands of steps: same regime, not same numbers)
 
