@@ -1,6 +1,6 @@
 """Randomised sweep of the fused-kernel paths (k_abc / k_chain / four launches, SAC and TD3) against the oracle: observation
 and action dims, batch sizes on every column split, narrower hidden layers, trainer kwargs drawn at random.
-usage: python scratch/fuzz_fused.py [cases] [seed]"""
+usage: python scratch/fuzz_fused.py [cases] [seed] [b1024]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,8 @@ for c in range(cases):
     O = int(rs.choice([rs.randint(1, 113), rs.randint(113, 497)]))
     A = int(rs.randint(1, 17))
     B = int(rs.choice([1, rs.randint(2, 257), rs.randint(257, 530), 16 * rs.randint(33, 130), rs.randint(530, 1500)]))
+    if len(sys.argv) > 3 and sys.argv[3] == "b1024" and c % 2 == 0:      # every other case on the batch-1024 fused launch (step kind 4)
+        B, O, A = 1024, int(rs.randint(1, 58)), int(rs.randint(1, 8))
     hid = lambda: (256, 256) if rs.rand() < 0.6 else (int(rs.randint(1, 257)), int(rs.randint(1, 257)))
     hp, hq = hid(), hid()
     td3 = c % 4 == 3
