@@ -84,6 +84,19 @@ struct GDev {
     float *y, *qn;                  // Bellman target [n]; min Q(s, a_new) [n]
     const float *DA[2];             // actor-loss gradient w.r.t. a_new through Q1 / Q2 [n][A]
     float *DHD;                     // head gradient [n][2A]
+    // SAC, the layers of one or two dozen outputs ride in the elementwise kernels (no matrix-product launch for them):
+    const float *PHl; int KPl;      // the policy's last hidden activations [2n][KPl]
+    const float *Wh, *bh;           // its merged head layer [2A][KPl], [2A]
+    float *HDw;                     // (HD as this step's head kernel writes it)
+    const float *QHl[2], *THl[2];   // last hidden activations of Q1, Q2 [2n][KQl] and of the targets [n][KQl]
+    int KQl;
+    const float *Wl[4], *bl[4];     // last layers (one output) of Q1, Q2, T1, T2: [KQl], [1]
+    float *QOw[4];
+    float *dQZl[2];                 // dL/d(last hidden) of Q1, Q2 [2n][KQl]
+    const float *dQZ0[2]; int HQ0;  // dL/d(first hidden) of Q1, Q2 [2n][HQ0] (the actor rows start at n)
+    const float *W1q[2];            // their first layers [HQ0][O + A]
+    float *DAw[2];
+    float *dPZl;                    // dL/d(the policy's last hidden) [n][KPl]
     float *diag_first, *diag_last, *diag_trace, *diag_dev;
     const float *eps1, *eps2;
     // TD3 (algo 1; rlkit TD3Trainer): XQ holds [(s, a) ; (s', a~)]; QO = {Q1, Q2 on (s, a), target Q1, Q2 on (s', a~)} [n] each
@@ -401,13 +414,18 @@ __global__ __launch_bounds__(64 * GW) void k_g_gemm(GemmStage T) {
 // ------------------------------------------------------------------------------------------
 // elementwise kernels
 // ------------------------------------------------------------------------------------------
-// TanhGaussianPolicy.forward(reparameterize=True, return_log_prob=True) behind the head layer, both passes: one thread
-// per row (side 0: policy(s), side 1: policy(s')).  The kernel also assembles the Q nets' input rows -- the torch.cat of
+// TanhGaussianPolicy.forward(reparameterize=True, return_log_prob=True) INCLUDING its head layer, both passes: one workgroup
+// per GRW rows (rows 0 .. n-1: policy(s), n .. 2n-1: policy(s')).  The head layer -- mean and log-std rows merged, 2A <= 32 outputs
+// -- is no matrix-product launch of its own: thread (kg, j) = (t >> 4, t & 15) contracts the inputs k = kg, kg + 16, ... for
+// outputs j (mean) and A + j (log-std), the sixteen partials meet in LDS in a fixed order, and threads 0 .. 15 go on as
+// (row, action).  The kernel also assembles the Q nets' input rows -- the torch.cat of
 // FlattenMlp: [obs|act ; obs|a_new ; next_obs|a'] -- and its LAST workgroup to finish takes the entropy step (SURVEY
 // Appendix A lines 4-6: alpha_loss = -mean(log_alpha (log_pi + H)), one Adam step on log_alpha, alpha = exp(.) post-step;
 // the sum runs in a fixed order).  Rows written by other workgroups are read back through agent-scope loads.
+constexpr int GRW = 4;      // rows per workgroup of the kernels that hold a small layer (weights loaded once per GRW rows)
 __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    __shared__ float part[GRW][16][33];
     {
         const int w = 2 * O + A, tot = n * w;               // (32-bit: checked at creation)
         for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < tot; e += (int)(gridDim.x * 256)) {
@@ -423,15 +441,43 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
             }
         }
     }
-    // thread = (row, action): 16 lanes per row (A <= 16), the row's log-prob by a 16-lane butterfly
-    const int r = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
-    if (r < 2 * n) {
+    // rows GRW blockIdx .. + GRW - 1: every weight is loaded once for the GRW rows
+    const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    {
+        const int K = d.KPl;
+        const float *wm = d.Wh + (long long)(a < A ? a : 0) * K, *wr = d.Wh + (long long)(A + (a < A ? a : 0)) * K;
+        const float *x[GRW];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) x[q] = d.PHl + (long long)(r0 + q < 2 * n ? r0 + q : r0) * K;
+        float sm[GRW], sr[GRW];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) { sm[q] = 0.f; sr[q] = 0.f; }
+        // (unrolled: the loads of several iterations are in flight together -- one memory latency per group instead of per iteration)
+#pragma unroll 8
+        for (int k = kg; k < K; k += 16) {
+            const float wmv = wm[k], wrv = wr[k];
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) {
+                const float xv = x[q][k];
+                sm[q] = fmaf(xv, wmv, sm[q]);
+                sr[q] = fmaf(xv, wrv, sr[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) { part[q][kg][a] = sm[q]; part[q][kg][16 + a] = sr[q]; }
+    }
+    __syncthreads();
+    const int rr = threadIdx.x >> 4, r = r0 + rr;
+    if (rr < GRW && r < 2 * n) {
         const int side = r >= n ? 1 : 0, b = r - side * n;
         const float *epp = side ? d.eps2 : d.eps1;
-        const float *hd = d.HD + (long long)r * 2 * A;
         float lp = 0.f;
         if (a < A) {
-            const float mean = hd[a], raw = hd[A + a];
+            float mean = part[rr][0][a], raw = part[rr][0][16 + a];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) { mean += part[rr][q][a]; raw += part[rr][q][16 + a]; }      // fixed order
+            mean += d.bh[a]; raw += d.bh[A + a];
+            d.HDw[(long long)r * 2 * A + a] = mean; d.HDw[(long long)r * 2 * A + A + a] = raw;
             const float lstd = fminf(fmaxf(raw, LOG_SIG_MIN), LOG_SIG_MAX);
             const float stdv = expf(lstd);
             const float eps = epp ? epp[(long long)b * A + a]
@@ -489,39 +535,129 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
     c->log_alpha = nla; c->a_m = m; c->a_v = v; c->alpha = expf(nla);
 }
 
-// min over the twin nets (actor loss, target), the Bellman target, and dL/dq of the passes that carry a gradient:
-// critic rows 2 (q - y) / n, actor rows -1/n to the smaller of Q1, Q2(s, a_new) (torch.min: a tie splits it)
+// One workgroup per batch row b.  The Q nets' LAST layers (one output each: a dot product over the last hidden layer -- Q1, Q2
+// on (s, a) and (s, a_new), the targets on (s', a')), then the min over the twin nets (actor loss, target), the Bellman target
+// and dL/dq of the passes that carry a gradient -- critic rows 2 (q - y) / n, actor rows -1/n to the smaller of Q1, Q2(s, a_new)
+// (torch.min: a tie splits it) -- and the backward pass through those last layers: dL/dh = dq w where h > 0.  Three launches
+// (a matrix product with ONE output column, this kernel, a matrix product with a reduction of length one) as one.
 __global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict__ S, SlotLayout SL) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= d.n) return;
-    const int n = d.n;
-    const float invB = 1.0f / (float)n;
-    const float alpha = d.ctl->alpha;
-    const float q1 = d.QO[0][b], q2 = d.QO[1][b], qa = d.QO[0][n + b], qb = d.QO[1][n + b];
-    const float tq = fminf(d.QO[2][b], d.QO[3][b]) - alpha * d.logpi2[b];
-    const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, tq);
-    d.y[b] = y;
-    d.qn[b] = fminf(qa, qb);
-    d.DQ[0][b] = 2.0f * (q1 - y) * invB;
-    d.DQ[1][b] = 2.0f * (q2 - y) * invB;
-    const float sel1 = (qa < qb) ? 1.0f : ((qa == qb) ? 0.5f : 0.0f);
-    d.DQ[0][n + b] = -invB * sel1;
-    d.DQ[1][n + b] = -invB * (1.0f - sel1);
+    const int b = blockIdx.x, n = d.n, K = d.KQl;
+    __shared__ float red[4][8];
+    __shared__ float s_dq[4];
+    const float *h[6] = {d.QHl[0] + (long long)b * K, d.QHl[0] + (long long)(n + b) * K, d.QHl[1] + (long long)b * K,
+                         d.QHl[1] + (long long)(n + b) * K, d.THl[0] + (long long)b * K, d.THl[1] + (long long)b * K};
+    const float *w[6] = {d.Wl[0], d.Wl[0], d.Wl[1], d.Wl[1], d.Wl[2], d.Wl[3]};
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = threadIdx.x; k < K; k += 256) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] = fmaf(h[q][k], w[q][k], acc[q]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+        if (lane == 0) red[wave][q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) v[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));      // fixed order
+        const float q1 = v[0] + d.bl[0][0], qa = v[1] + d.bl[0][0], q2 = v[2] + d.bl[1][0], qb = v[3] + d.bl[1][0];
+        const float t1 = v[4] + d.bl[2][0], t2 = v[5] + d.bl[3][0];
+        const float invB = 1.0f / (float)n;
+        const float alpha = d.ctl->alpha;
+        const float tq = fminf(t1, t2) - alpha * d.logpi2[b];
+        const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, tq);
+        d.QOw[0][b] = q1; d.QOw[0][n + b] = qa; d.QOw[1][b] = q2; d.QOw[1][n + b] = qb; d.QOw[2][b] = t1; d.QOw[3][b] = t2;
+        d.y[b] = y;
+        d.qn[b] = fminf(qa, qb);
+        const float sel1 = (qa < qb) ? 1.0f : ((qa == qb) ? 0.5f : 0.0f);
+        const float g0 = 2.0f * (q1 - y) * invB, g1 = 2.0f * (q2 - y) * invB, g2 = -invB * sel1, g3 = -invB * (1.0f - sel1);
+        d.DQ[0][b] = g0; d.DQ[1][b] = g1; d.DQ[0][n + b] = g2; d.DQ[1][n + b] = g3;
+        s_dq[0] = g0; s_dq[1] = g2; s_dq[2] = g1; s_dq[3] = g3;          // in the order of h[0 .. 3]
+    }
+    __syncthreads();
+    float *o[4] = {d.dQZl[0] + (long long)b * K, d.dQZl[0] + (long long)(n + b) * K, d.dQZl[1] + (long long)b * K,
+                   d.dQZl[1] + (long long)(n + b) * K};
+    for (int k = threadIdx.x; k < K; k += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][k] = (h[q][k] > 0.f) ? s_dq[q] * w[q][k] : 0.f;
+    }
 }
 
-// d/d(mean, log_std) of mean(alpha log_pi - min Q) through a = tanh(mean + std eps)
+// One workgroup per GRW batch rows: the actor-loss gradient w.r.t. a_new through the FIRST layers of Q1 and Q2 (the action columns
+// of W1: a dot product over the first hidden layer per action), d/d(mean, log_std) of mean(alpha log_pi - min Q) through
+// a = tanh(mean + std eps), and the backward pass through the policy's head layer (2A terms per hidden unit, masked).  Three
+// launches (a matrix product with A output columns, the elementwise kernel, a matrix product with a reduction of length 2A) as one.
 __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)d.n * d.A) return;
-    const int b = (int)(e / d.A), a = (int)(e % d.A);
-    const float alpha_invB = __fmul_rn(d.ctl->alpha, 1.0f / (float)d.n);
-    const float da = d.DA[0][e] + d.DA[1][e];
-    const float act = d.anew[e];
-    const float om = 1.0f - act * act;
-    const float dz = actor_dz(da, om, alpha_invB, act);
-    const float dls = actor_dls(dz, expf(d.ls[e]), d.epsv[e], alpha_invB, d.ok[e]);
-    d.DHD[(long long)b * 2 * d.A + a] = dz;
-    d.DHD[(long long)b * 2 * d.A + d.A + a] = dls;
+    const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq;
+    __shared__ float part[GRW][16][33];
+    __shared__ float dhd[GRW][32];
+    const int a = threadIdx.x & 15, hg = threadIdx.x >> 4;
+    {
+        const float *w0 = d.W1q[0] + d.O + (a < A ? a : 0), *w1 = d.W1q[1] + d.O + (a < A ? a : 0);
+        const float *g0[GRW], *g1[GRW];
+        float s0[GRW], s1[GRW];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) {
+            const int b = b0 + q < n ? b0 + q : b0;
+            g0[q] = d.dQZ0[0] + (long long)(n + b) * H0; g1[q] = d.dQZ0[1] + (long long)(n + b) * H0;
+            s0[q] = 0.f; s1[q] = 0.f;
+        }
+#pragma unroll 8
+        for (int hh = hg; hh < H0; hh += 16) {
+            const float w0v = w0[(long long)hh * ldq], w1v = w1[(long long)hh * ldq];
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) {
+                s0[q] = fmaf(g0[q][hh], w0v, s0[q]);
+                s1[q] = fmaf(g1[q][hh], w1v, s1[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) { part[q][hg][a] = s0[q]; part[q][hg][16 + a] = s1[q]; }
+    }
+    if (threadIdx.x < GRW * 32) dhd[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+    __syncthreads();
+    const int rr = threadIdx.x >> 4;
+    if (rr < GRW && b0 + rr < n && a < A) {
+        const int b = b0 + rr;
+        float da0 = part[rr][0][a], da1 = part[rr][0][16 + a];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { da0 += part[rr][q][a]; da1 += part[rr][q][16 + a]; }          // fixed order
+        const long long e = (long long)b * A + a;
+        d.DAw[0][e] = da0; d.DAw[1][e] = da1;
+        const float alpha_invB = __fmul_rn(d.ctl->alpha, 1.0f / (float)n);
+        const float da = da0 + da1;
+        const float act = d.anew[e];
+        const float om = 1.0f - act * act;
+        const float dz = actor_dz(da, om, alpha_invB, act);
+        const float dls = actor_dls(dz, expf(d.ls[e]), d.epsv[e], alpha_invB, d.ok[e]);
+        d.DHD[(long long)b * 2 * A + a] = dz;
+        d.DHD[(long long)b * 2 * A + A + a] = dls;
+        dhd[rr][a] = dz; dhd[rr][A + a] = dls;
+    }
+    __syncthreads();
+    const int K = d.KPl;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float sacc[GRW];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) sacc[q] = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < 2 * A; ++j) {
+            const float wv = d.Wh[(long long)j * K + k];
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wv, sacc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < GRW; ++q)
+            if (b0 + q < n) {
+                const long long off = (long long)(b0 + q) * K + k;
+                d.dPZl[off] = (d.PHl[off] > 0.f) ? sacc[q] : 0.f;
+            }
+    }
 }
 
 __device__ void diag_block(const GDev &d, const StepArg &sa);

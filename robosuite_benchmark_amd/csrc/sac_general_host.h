@@ -258,12 +258,19 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         }
         end();
     }
-    {
-        const GenLayer &L = g->net[0].L[Lp];
-        begin(0); add(gen_fwd(PH[Lp - 1], 2 * n, Wp(0, Lp), Bp(0, Lp), L.N, L.K, HD, 0)); end();
+    // (the head layer -- 2A outputs -- is computed inside the head kernel, the Q nets' last layers -- one output -- inside the
+    //  loss kernel together with their backward pass, the action columns of the Q nets' first layers and the head layer's
+    //  backward pass inside the policy-gradient kernel: five matrix-product launches fewer per step than one per layer and
+    //  direction, each of which had a handful of output columns or a reduction of a handful of terms)
+    d.PHl = PH[Lp - 1]; d.KPl = hp[Lp - 1]; d.Wh = Wp(0, Lp); d.bh = Bp(0, Lp); d.HDw = HD;
+    for (int k = 0; k < 2; ++k) {
+        d.QHl[k] = QH[k][Lq - 1]; d.THl[k] = TH[k][Lq - 1]; d.dQZl[k] = dQZ[k][Lq - 1];
+        d.dQZ0[k] = dQZ[k][0]; d.W1q[k] = Wp(1 + k, 0); d.DAw[k] = DA[k];
     }
+    d.KQl = hq[Lq - 1]; d.HQ0 = hq[0]; d.dPZl = dPZ[Lp - 1];
+    for (int k = 0; k < 4; ++k) { d.Wl[k] = Wp(1 + k, Lq); d.bl[k] = Bp(1 + k, Lq); d.QOw[k] = QO[k]; }
     plain(GS_HEAD);
-    for (int l = 0; l <= Lq; ++l) {                      // Q1, Q2 on [(s,a) ; (s,a_new)], targets on (s',a')
+    for (int l = 0; l < Lq; ++l) {                       // Q1, Q2 on [(s,a) ; (s,a_new)], targets on (s',a'): the hidden layers
         begin(0);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[l];
@@ -278,24 +285,18 @@ int gen_build(sac_trainer *t, const int *hp, int np_, const int *hq, int nq_) {
         end();
     }
     plain(GS_LOSS);
-    for (int j = Lq; j >= 1; --j) {                      // backward through layer j of Q1, Q2 (critic and actor rows)
+    for (int j = Lq - 1; j >= 1; --j) {                  // backward through hidden layer j of Q1, Q2 (critic and actor rows)
         begin(1);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[j];
-            add(gen_bwd(j == Lq ? d.DQ[k] : dQZ[k][j], 2 * n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
+            add(gen_bwd(dQZ[k][j], 2 * n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
         }
         end();
     }
-    begin(1);                                             // the actor rows' gradient w.r.t. the action columns of the input
-    for (int k = 0; k < 2; ++k) {
-        const GenLayer &L = g->net[1 + k].L[0];
-        add(gen_bwd(dQZ[k][0] + (long long)n * L.N, n, L.N, Wp(1 + k, 0), L.K, O, A, DA[k], A, nullptr, 0));
-    }
-    end();
     plain(GS_POLGRAD);
-    for (int j = Lp; j >= 1; --j) {                      // backward through the policy (rows of s only)
+    for (int j = Lp - 1; j >= 1; --j) {                  // backward through the policy's hidden layers (rows of s only)
         const GenLayer &L = g->net[0].L[j];
-        begin(1); add(gen_bwd(j == Lp ? d.DHD : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PH[j - 1], L.K)); end();
+        begin(1); add(gen_bwd(dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PH[j - 1], L.K)); end();
     }
     begin(2);                                             // every weight gradient of the step
     for (int l = Lp; l >= 0; --l) {
@@ -512,9 +513,10 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
             else hipLaunchKernelGGL((gen::k_g_gemm<false, false>), grid, dim3(64 * gen::GW), 0, s, gs);
             break;
         }
-        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, head_grid(2 * n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
-        case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
-        case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
+        // (SAC: one workgroup per row / per GRW rows -- the kernels hold the layers of a handful of outputs, see gen_build)
+        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, dim3((2 * n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa); break;
+        case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(n), dim3(256), 0, s, d, S, SL); break;
+        case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d); break;
         case GS_DIAG:       // (SAC: on the steps whose diagnostics somebody reads -- the first and the last of a loop, single steps)
             if (t->algo == 1 || (sa.pad2 & 2u) || sa.loop_pos == 0) hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa);
             break;
