@@ -694,7 +694,7 @@ def device_report(args, trainer, buf, task, O, A, B, world, value, elapsed_max, 
                                                step_kind=tg.fused_mode(), finite=bool(np.all(np.isfinite(last_g))),
                                                gflop_per_step=round(gflop, 3), tflops=round(gflop * n_g / dt * 1e-3, 2))
             del tg
-        out["general_step"] = dict(shapes=gs, note="hidden_sizes beyond two layers of <= 256 units: one launch per layer and pass "
+        out["general_step"] = dict(shapes=gs, note="hidden_sizes beyond two layers of <= 256 units: one launch per hidden layer and pass "
                                                    "direction (csrc/sac_general.h); steps include the index draw and the gather")
         buf.seed(17)
     if world == 1 and args.replicas_per_gpu > 1:

@@ -213,7 +213,7 @@ int sac_trainer_create(sac_trainer_t **out, const sac_config_t *cfg);
  * FlattenMlp / TanhGaussianPolicy take a list of any length: /root/reference/util/rlkit_utils.py:64-97): 1..7 hidden layers
  * of 1..4096 units per network family (cfg->hidden / policy_hidden / qf_hidden are ignored).  Two hidden layers of at most
  * 256 units -- every shipped variant.json -- run on the fused kernels exactly as with sac_trainer_create; every other shape
- * runs the GENERAL step: the same step in the same order as a sequence of 2 Lp + 2 Lq + 11 launches around one
+ * runs the GENERAL step: the same step in the same order as a sequence of 2 Lp + 2 Lq + 2 launches around one
  * matrix-product kernel (csrc/sac_general.h), results within fp32 round-off of the oracle like the fused kernels'
  * (tests/test_gpu_general_shapes.py); sac_trainer_step_kind reports 3.  Every sac_* entry point works on such a handle except
  * sac_profile_loop.  (TD3: td3_trainer_create_mlp.) */

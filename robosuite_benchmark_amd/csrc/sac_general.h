@@ -9,14 +9,17 @@
 //                extra column of ones) -- as a table of jobs per launch: a launch carries every network's job of one
 //                stage (Q1, Q2 and both targets' layer l are ONE launch).  64 x 64 output tiles, fp32 MFMA 16x16x4,
 //                operands staged through LDS with generic strides.
-//   k_g_head     tanh-Gaussian head on both policy passes (rsample, log-prob); the Q nets' input rows
-//                [obs|act ; obs|a_new ; next_obs|a']; its last workgroup: mean(log_pi) -> Adam step on log_alpha
-//   k_g_loss     min over the twin nets, Bellman target, the loss gradients of the four Q passes that have one
-//   k_g_polgrad  head gradient of the reparameterised actor loss
+//   k_g_head     the policy's head layer (2A outputs) and the tanh-Gaussian head on both policy passes (rsample, log-prob); the
+//                Q nets' input rows [obs|act ; obs|a_new ; next_obs|a']; its last workgroup: mean(log_pi) -> Adam step on log_alpha
+//   k_g_loss     the Q nets' last layers (one output), min over the twin nets, Bellman target, the loss gradients of the four
+//                Q passes that have one, and the backward pass through those last layers
+//   k_g_polgrad  dQ/da through the action columns of the Q nets' first layers, head gradient of the reparameterised actor loss,
+//                backward pass through the head layer
 //   k_g_diag     the diagnostics vector (Adam and the Polyak average run in the weight-gradient launch's epilogue: a tile's
 //                owner updates the parameters it owns)
 // Weights live in nn.Linear layout (W [out][in] row-major, then b), activations row-major [row][feature]; rows = the
-// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 7 launches per step (15 for two hidden layers; + one for the diagnostics on the steps somebody reads them): this path is for
+// TRUE batch (no row-block padding).  2 Lp + 2 Lq + 2 launches per step (10 for two hidden layers; + one for the diagnostics on the steps somebody reads
+// them; SAC: the layers of a handful of outputs ride in k_g_head / k_g_loss / k_g_polgrad, TD3 still gives each a matrix-product launch): this path is for
 // shapes the reference can be configured with but no shipped variant uses -- the shipped ones take the fused kernels.
 #pragma once
 
