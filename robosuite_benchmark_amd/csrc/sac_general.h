@@ -426,9 +426,12 @@ __global__ __launch_bounds__(64 * GW) void k_g_gemm(GemmStage T) {
 // Appendix A lines 4-6: alpha_loss = -mean(log_alpha (log_pi + H)), one Adam step on log_alpha, alpha = exp(.) post-step;
 // the sum runs in a fixed order).  Rows written by other workgroups are read back through agent-scope loads.
 constexpr int GRW = 4;      // rows per workgroup of the kernels that hold a small layer (weights loaded once per GRW rows)
+constexpr int GCK = 256;    // their reduction chunk: one column per thread
 __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     __shared__ float part[GRW][16][33];
+    __shared__ float xs[GRW][GCK];
+    __shared__ float ws[32][GCK + 1];
     {
         const int w = 2 * O + A, tot = n * w;               // (32-bit: checked at creation)
         for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < tot; e += (int)(gridDim.x * 256)) {
@@ -444,26 +447,45 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
             }
         }
     }
-    // rows GRW blockIdx .. + GRW - 1: every weight is loaded once for the GRW rows
+    // rows GRW blockIdx .. + GRW - 1: every weight is loaded once for the GRW rows.  The reduction runs in chunks of GCK inputs
+    // staged through LDS: a thread fetches ONE column of the chunk -- its GRW activations and 2A weights, every load
+    // independent and coalesced, the next chunk's in flight under this chunk's arithmetic -- so a chunk costs one memory
+    // latency (the loop that loaded where it multiplied, sixteen strided rows per wave-load and a latency per iteration, took
+    // 12 us at 512 inputs under rocprofv3).
     const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, kg = threadIdx.x >> 4;
     {
-        const int K = d.KPl;
-        const float *wm = d.Wh + (long long)(a < A ? a : 0) * K, *wr = d.Wh + (long long)(A + (a < A ? a : 0)) * K;
-        const float *x[GRW];
-#pragma unroll
-        for (int q = 0; q < GRW; ++q) x[q] = d.PHl + (long long)(r0 + q < 2 * n ? r0 + q : r0) * K;
-        float sm[GRW], sr[GRW];
+        const int K = d.KPl, t = threadIdx.x, nj = 2 * A;
+        float sm[GRW], sr[GRW], rx[GRW], rw[32];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) { sm[q] = 0.f; sr[q] = 0.f; }
-        // (unrolled: the loads of several iterations are in flight together -- one memory latency per group instead of per iteration)
-#pragma unroll 8
-        for (int k = kg; k < K; k += 16) {
-            const float wmv = wm[k], wrv = wr[k];
+        auto fetch = [&](int k0) {
+            const int k = k0 + t;
+            const bool in = k < K;
 #pragma unroll
-            for (int q = 0; q < GRW; ++q) {
-                const float xv = x[q][k];
-                sm[q] = fmaf(xv, wmv, sm[q]);
-                sr[q] = fmaf(xv, wrv, sr[q]);
+            for (int q = 0; q < GRW; ++q) rx[q] = in ? d.PHl[(long long)(r0 + q < 2 * n ? r0 + q : r0) * K + k] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) rw[j] = (j < nj && in) ? d.Wh[(long long)j * K + k] : 0.f;
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < K; k0 += GCK) {
+            __syncthreads();                              // (the previous chunk's readers are done)
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) xs[q][t] = rx[q];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) if (j < nj) ws[j][t] = rw[j];
+            __syncthreads();
+            if (k0 + GCK < K) fetch(k0 + GCK);
+            const float *wmr = ws[a < A ? a : 0], *wrr = ws[A + (a < A ? a : 0)];
+#pragma unroll
+            for (int i = 0; i < GCK / 16; ++i) {
+                const int kk = kg + 16 * i;
+                const float wmv = wmr[kk], wrv = wrr[kk];
+#pragma unroll
+                for (int q = 0; q < GRW; ++q) {
+                    const float xv = xs[q][kk];
+                    sm[q] = fmaf(xv, wmv, sm[q]);
+                    sr[q] = fmaf(xv, wrv, sr[q]);
+                }
             }
         }
 #pragma unroll
@@ -551,6 +573,13 @@ __global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict_
                          d.QHl[1] + (long long)(n + b) * K, d.THl[0] + (long long)b * K, d.THl[1] + (long long)b * K};
     const float *w[6] = {d.Wl[0], d.Wl[0], d.Wl[1], d.Wl[1], d.Wl[2], d.Wl[3]};
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (thread 0's scalars are requested with the first operands: they would otherwise cost a memory latency behind the reduction)
+    float p_alpha = 0.f, p_lp2 = 0.f, p_rew = 0.f, p_term = 0.f, p_b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x == 0) {
+        p_alpha = d.ctl->alpha; p_lp2 = d.logpi2[b]; p_rew = S[SL.off_rew + b]; p_term = S[SL.off_term + b];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p_b[q] = d.bl[q][0];
+    }
 #pragma unroll 4
     for (int k = threadIdx.x; k < K; k += 256) {
 #pragma unroll
@@ -568,12 +597,11 @@ __global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict_
         float v[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) v[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));      // fixed order
-        const float q1 = v[0] + d.bl[0][0], qa = v[1] + d.bl[0][0], q2 = v[2] + d.bl[1][0], qb = v[3] + d.bl[1][0];
-        const float t1 = v[4] + d.bl[2][0], t2 = v[5] + d.bl[3][0];
+        const float q1 = v[0] + p_b[0], qa = v[1] + p_b[0], q2 = v[2] + p_b[1], qb = v[3] + p_b[1];
+        const float t1 = v[4] + p_b[2], t2 = v[5] + p_b[3];
         const float invB = 1.0f / (float)n;
-        const float alpha = d.ctl->alpha;
-        const float tq = fminf(t1, t2) - alpha * d.logpi2[b];
-        const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, tq);
+        const float tq = fminf(t1, t2) - p_alpha * p_lp2;
+        const float y = bellman_target(d.reward_scale, p_rew, p_term, d.discount, tq);
         d.QOw[0][b] = q1; d.QOw[0][n + b] = qa; d.QOw[1][b] = q2; d.QOw[1][n + b] = qb; d.QOw[2][b] = t1; d.QOw[3][b] = t2;
         d.y[b] = y;
         d.qn[b] = fminf(qa, qb);
@@ -596,70 +624,128 @@ __global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict_
 // a = tanh(mean + std eps), and the backward pass through the policy's head layer (2A terms per hidden unit, masked).  Three
 // launches (a matrix product with A output columns, the elementwise kernel, a matrix product with a reduction of length 2A) as one.
 __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
-    const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq;
+    const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq, t = threadIdx.x;
     __shared__ float part[GRW][16][33];
     __shared__ float dhd[GRW][32];
-    const int a = threadIdx.x & 15, hg = threadIdx.x >> 4;
+    __shared__ float gs[GRW][2][GCK];          // dL/d(first hidden) of Q1 | Q2, the actor rows of this workgroup, one chunk
+    __shared__ float was[2][GCK][17];          // the action columns of W1 (Q1 | Q2), one chunk of hidden units
+    const int a = t & 15, hg = t >> 4;
+    // Everything that does not depend on dQ/da is requested FIRST (the kernel is a chain of dependent phases, each of which
+    // would otherwise start with a cold memory latency of its own: 14.7 us under rocprofv3 for a few hundred kFLOP): the head
+    // layer's weights and the relu masks of this thread's first hidden unit of the last phase, and what the sixteen
+    // (row, action) threads per row need from the head kernel.
+    const int K = d.KPl, nj = 2 * A;
+    float wv[32], hm[GRW];
     {
-        const float *w0 = d.W1q[0] + d.O + (a < A ? a : 0), *w1 = d.W1q[1] + d.O + (a < A ? a : 0);
-        const float *g0[GRW], *g1[GRW];
-        float s0[GRW], s1[GRW];
+        const int k = t < K ? t : 0;
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) {
-            const int b = b0 + q < n ? b0 + q : b0;
-            g0[q] = d.dQZ0[0] + (long long)(n + b) * H0; g1[q] = d.dQZ0[1] + (long long)(n + b) * H0;
-            s0[q] = 0.f; s1[q] = 0.f;
-        }
-#pragma unroll 8
-        for (int hh = hg; hh < H0; hh += 16) {
-            const float w0v = w0[(long long)hh * ldq], w1v = w1[(long long)hh * ldq];
+        for (int j = 0; j < 32; ++j) wv[j] = (j < nj) ? d.Wh[(long long)j * K + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k];
+    }
+    const int rr = t >> 4;
+    const bool head_thread = rr < GRW && b0 + rr < n && a < A;
+    float p_act = 0.f, p_ls = 0.f, p_eps = 0.f, p_ok = 0.f, p_alpha = 0.f;
+    if (head_thread) {
+        const long long e = (long long)(b0 + rr) * A + a;
+        p_act = d.anew[e]; p_ls = d.ls[e]; p_eps = d.epsv[e]; p_ok = d.ok[e]; p_alpha = d.ctl->alpha;
+    }
+    {   // dQ/da: chunks of GCK hidden units through LDS (a thread fetches one hidden unit: 2 GRW gradients, 2 A weights)
+        // (the A action columns of a chunk's GCK rows of W1 are fetched as the flat sequence (row, column): consecutive lanes read
+        //  consecutive columns of a row, then the next row -- a wave-load touches ~64 / A rows.  One row per lane, the first
+        //  cut, touched 64 rows per wave-load: 64 cache lines per instruction, 8 us of the kernel's 15.)
+        float s0[GRW], s1[GRW], rg[GRW][2], rwa[2][16];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+        auto fetch = [&](int h0) {
+            const int hh = h0 + t;
+            const bool in = hh < H0;
 #pragma unroll
             for (int q = 0; q < GRW; ++q) {
-                s0[q] = fmaf(g0[q][hh], w0v, s0[q]);
-                s1[q] = fmaf(g1[q][hh], w1v, s1[q]);
+                const long long row = (long long)(n + (b0 + q < n ? b0 + q : b0)) * H0 + hh;
+                rg[q][0] = in ? d.dQZ0[0][row] : 0.f; rg[q][1] = in ? d.dQZ0[1][row] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {                  // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
+                const int e = t + 256 * m, hl = e / A, j = e - hl * A;
+                const bool ok = m < A && h0 + hl < H0;
+                rwa[0][m] = ok ? d.W1q[0][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
+                rwa[1][m] = ok ? d.W1q[1][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
+            }
+        };
+        fetch(0);
+        for (int h0 = 0; h0 < H0; h0 += GCK) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) { gs[q][0][t] = rg[q][0]; gs[q][1][t] = rg[q][1]; }
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m < A) {
+                    const int e = t + 256 * m, hl = e / A, j = e - hl * A;
+                    was[0][hl][j] = rwa[0][m]; was[1][hl][j] = rwa[1][m];
+                }
+            __syncthreads();
+            if (h0 + GCK < H0) fetch(h0 + GCK);
+#pragma unroll
+            for (int i = 0; i < GCK / 16; ++i) {
+                const int hl = hg + 16 * i;
+                const float w0v = was[0][hl][a], w1v = was[1][hl][a];
+#pragma unroll
+                for (int q = 0; q < GRW; ++q) {
+                    s0[q] = fmaf(gs[q][0][hl], w0v, s0[q]);
+                    s1[q] = fmaf(gs[q][1][hl], w1v, s1[q]);
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < GRW; ++q) { part[q][hg][a] = s0[q]; part[q][hg][16 + a] = s1[q]; }
     }
-    if (threadIdx.x < GRW * 32) dhd[threadIdx.x >> 5][threadIdx.x & 31] = 0.f;
+    if (t < GRW * 32) dhd[t >> 5][t & 31] = 0.f;
     __syncthreads();
-    const int rr = threadIdx.x >> 4;
-    if (rr < GRW && b0 + rr < n && a < A) {
+    if (head_thread) {
         const int b = b0 + rr;
         float da0 = part[rr][0][a], da1 = part[rr][0][16 + a];
 #pragma unroll
         for (int q = 1; q < 16; ++q) { da0 += part[rr][q][a]; da1 += part[rr][q][16 + a]; }          // fixed order
         const long long e = (long long)b * A + a;
         d.DAw[0][e] = da0; d.DAw[1][e] = da1;
-        const float alpha_invB = __fmul_rn(d.ctl->alpha, 1.0f / (float)n);
+        const float alpha_invB = __fmul_rn(p_alpha, 1.0f / (float)n);
         const float da = da0 + da1;
-        const float act = d.anew[e];
+        const float act = p_act;
         const float om = 1.0f - act * act;
         const float dz = actor_dz(da, om, alpha_invB, act);
-        const float dls = actor_dls(dz, expf(d.ls[e]), d.epsv[e], alpha_invB, d.ok[e]);
+        const float dls = actor_dls(dz, expf(p_ls), p_eps, alpha_invB, p_ok);
         d.DHD[(long long)b * 2 * A + a] = dz;
         d.DHD[(long long)b * 2 * A + A + a] = dls;
         dhd[rr][a] = dz; dhd[rr][A + a] = dls;
     }
     __syncthreads();
-    const int K = d.KPl;
-    for (int k = threadIdx.x; k < K; k += 256) {
+    // backward through the head layer: a thread owns hidden unit k -- its 2A weights and GRW masks in one round of loads (the
+    // first unit's came in at the start; the next unit's are requested before this one's arithmetic)
+    for (int k = t; k < K; k += 256) {
+        float wc[32], hc[GRW];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wc[j] = wv[j];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) hc[q] = hm[q];
+        if (k + 256 < K) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) wv[j] = (j < nj) ? d.Wh[(long long)j * K + k + 256] : 0.f;
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k + 256];
+        }
         float sacc[GRW];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) sacc[q] = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < 2 * A; ++j) {
-            const float wv = d.Wh[(long long)j * K + k];
 #pragma unroll
-            for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wv, sacc[q]);
-        }
+        for (int j = 0; j < 32; ++j)
+            if (j < nj) {
+#pragma unroll
+                for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wc[j], sacc[q]);
+            }
 #pragma unroll
         for (int q = 0; q < GRW; ++q)
-            if (b0 + q < n) {
-                const long long off = (long long)(b0 + q) * K + k;
-                d.dPZl[off] = (d.PHl[off] > 0.f) ? sacc[q] : 0.f;
-            }
+            if (b0 + q < n) d.dPZl[(long long)(b0 + q) * K + k] = (hc[q] > 0.f) ? sacc[q] : 0.f;
     }
 }
 
