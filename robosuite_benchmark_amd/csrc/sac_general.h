@@ -19,7 +19,7 @@
 //                owner updates the parameters it owns)
 // Weights live in nn.Linear layout (W [out][in] row-major, then b), activations row-major [row][feature]; rows = the
 // TRUE batch (no row-block padding).  2 Lp + 2 Lq + 2 launches per step (10 for two hidden layers; + one for the diagnostics on the steps somebody reads
-// them; SAC: the layers of a handful of outputs ride in k_g_head / k_g_loss / k_g_polgrad, TD3 still gives each a matrix-product launch): this path is for
+// them; the layers of a handful of outputs ride in k_g_head / k_g_loss / k_g_polgrad and their TD3 counterparts): this path is for
 // shapes the reference can be configured with but no shipped variant uses -- the shipped ones take the fused kernels.
 #pragma once
 
@@ -111,6 +111,14 @@ struct GDev {
     float *DQA;                     // its loss gradient (-1/n) [n]
     const float *DAa;               // dL/da through Q1 [n][A]
     float *DHP;                     // head gradient [n][A]
+    // TD3, the small layers inside the elementwise kernels (as SAC's above; Wh / bh / KPl / PHl / dPZl / W1q[0] / Wl / bl / QOw / KQl /
+    // QHl / THl / dQZl are shared): the target policy's last hidden activations and head [A][KPl]; Q1's hidden activations on
+    // (s, pi(s)) and their gradients
+    const float *PHTl, *WhT, *bhT;
+    float *HDTw, *HDPw;
+    const float *AHl; float *dAZl;  // [n][KQl]
+    const float *dAZ0;              // [n][HQ0]
+    float *QAw, *DAaw;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -427,6 +435,56 @@ __global__ __launch_bounds__(64 * GW) void k_g_gemm(GemmStage T) {
 // the sum runs in a fixed order).  Rows written by other workgroups are read back through agent-scope loads.
 constexpr int GRW = 4;      // rows per workgroup of the kernels that hold a small layer (weights loaded once per GRW rows)
 constexpr int GCK = 256;    // their reduction chunk: one column per thread
+// A layer of at most 32 outputs on rows r0 .. r0 + GRW - 1 of X [nrows][K] (a policy's head layer), without a matrix-product
+// launch: thread (kg, j) = (t >> 4, t & 15) contracts the inputs k = kg, kg + 16, ... for output j (and, `two`, output A + j: the
+// log-std row of SAC's merged heads); the sixteen partials per output are left in part[row][kg][j | 16 + j] for the caller to
+// add in a fixed order.  Every weight is loaded once for the GRW rows.  The reduction runs in chunks of GCK inputs
+// staged through LDS: a thread fetches ONE column of the chunk -- its GRW activations and the outputs' weights, every load
+// independent and coalesced, the next chunk's in flight under this chunk's arithmetic -- so a chunk costs one memory
+// latency (a loop that loaded where it multiplied, sixteen strided rows per wave-load and a latency per iteration, took
+// 12 us at 512 inputs under rocprofv3).
+__device__ __forceinline__ void small_layer_rows(const float *X, int K, const float *W, int A, bool two, int r0, int nrows,
+                                                 float (*part)[16][33], float (*xs)[GCK], float (*ws)[GCK + 1]) {
+    const int a = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    const int t = threadIdx.x, nj = two ? 2 * A : A;
+    float sm[GRW], sr[GRW], rx[GRW], rw[32];
+#pragma unroll
+    for (int q = 0; q < GRW; ++q) { sm[q] = 0.f; sr[q] = 0.f; }
+    auto fetch = [&](int k0) {
+        const int k = k0 + t;
+        const bool in = k < K;
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) rx[q] = in ? X[(long long)(r0 + q < nrows ? r0 + q : r0) * K + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) rw[j] = (j < nj && in) ? W[(long long)j * K + k] : 0.f;
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += GCK) {
+        __syncthreads();                              // (the previous chunk's readers are done)
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) xs[q][t] = rx[q];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if (j < nj) ws[j][t] = rw[j];
+        __syncthreads();
+        if (k0 + GCK < K) fetch(k0 + GCK);
+        const float *wmr = ws[a < A ? a : 0], *wrr = ws[two ? A + (a < A ? a : 0) : 0];
+#pragma unroll
+        for (int i = 0; i < GCK / 16; ++i) {
+            const int kk = kg + 16 * i;
+            const float wmv = wmr[kk], wrv = wrr[kk];
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) {
+                const float xv = xs[q][kk];
+                sm[q] = fmaf(xv, wmv, sm[q]);
+                sr[q] = fmaf(xv, wrv, sr[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < GRW; ++q) { part[q][kg][a] = sm[q]; part[q][kg][16 + a] = sr[q]; }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     __shared__ float part[GRW][16][33];
@@ -447,51 +505,8 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
             }
         }
     }
-    // rows GRW blockIdx .. + GRW - 1: every weight is loaded once for the GRW rows.  The reduction runs in chunks of GCK inputs
-    // staged through LDS: a thread fetches ONE column of the chunk -- its GRW activations and 2A weights, every load
-    // independent and coalesced, the next chunk's in flight under this chunk's arithmetic -- so a chunk costs one memory
-    // latency (the loop that loaded where it multiplied, sixteen strided rows per wave-load and a latency per iteration, took
-    // 12 us at 512 inputs under rocprofv3).
-    const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, kg = threadIdx.x >> 4;
-    {
-        const int K = d.KPl, t = threadIdx.x, nj = 2 * A;
-        float sm[GRW], sr[GRW], rx[GRW], rw[32];
-#pragma unroll
-        for (int q = 0; q < GRW; ++q) { sm[q] = 0.f; sr[q] = 0.f; }
-        auto fetch = [&](int k0) {
-            const int k = k0 + t;
-            const bool in = k < K;
-#pragma unroll
-            for (int q = 0; q < GRW; ++q) rx[q] = in ? d.PHl[(long long)(r0 + q < 2 * n ? r0 + q : r0) * K + k] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) rw[j] = (j < nj && in) ? d.Wh[(long long)j * K + k] : 0.f;
-        };
-        fetch(0);
-        for (int k0 = 0; k0 < K; k0 += GCK) {
-            __syncthreads();                              // (the previous chunk's readers are done)
-#pragma unroll
-            for (int q = 0; q < GRW; ++q) xs[q][t] = rx[q];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) if (j < nj) ws[j][t] = rw[j];
-            __syncthreads();
-            if (k0 + GCK < K) fetch(k0 + GCK);
-            const float *wmr = ws[a < A ? a : 0], *wrr = ws[A + (a < A ? a : 0)];
-#pragma unroll
-            for (int i = 0; i < GCK / 16; ++i) {
-                const int kk = kg + 16 * i;
-                const float wmv = wmr[kk], wrv = wrr[kk];
-#pragma unroll
-                for (int q = 0; q < GRW; ++q) {
-                    const float xv = xs[q][kk];
-                    sm[q] = fmaf(xv, wmv, sm[q]);
-                    sr[q] = fmaf(xv, wrv, sr[q]);
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < GRW; ++q) { part[q][kg][a] = sm[q]; part[q][kg][16 + a] = sr[q]; }
-    }
-    __syncthreads();
+    const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15;
+    small_layer_rows(d.PHl, d.KPl, d.Wh, A, true, r0, 2 * n, part, xs, ws);
     const int rr = threadIdx.x >> 4, r = r0 + rr;
     if (rr < GRW && r < 2 * n) {
         const int side = r >= n ? 1 : 0, b = r - side * n;
@@ -834,6 +849,9 @@ __device__ void diag_block(const GDev &d, const StepArg &sa) {
 // (the sum is NOT clipped to the action range)
 __global__ __launch_bounds__(256) void k_g_td3_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    __shared__ float part[GRW][16][33];
+    __shared__ float xs[GRW][GCK];
+    __shared__ float ws[32][GCK + 1];
     {
         const int w = 2 * O + A, tot = n * w;
         for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < tot; e += (int)(gridDim.x * 256)) {
@@ -843,49 +861,218 @@ __global__ __launch_bounds__(256) void k_g_td3_head(GDev d, const float *__restr
             else d.XQ[(long long)b * ldq + O + (k - 2 * O)] = S[SL.off_act + (long long)b * A + (k - 2 * O)];
         }
     }
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
-    if (b < n && a < A) {
+    // the target policy's head layer (A outputs) on the GRW rows of this workgroup, then thread = (row, action)
+    const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, rr = threadIdx.x >> 4, b = r0 + rr;
+    small_layer_rows(d.PHTl, d.KPl, d.WhT, A, false, r0, n, part, xs, ws);
+    if (rr < GRW && b < n && a < A) {
+        float mean = part[rr][0][a];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) mean += part[rr][q][a];                                  // fixed order
+        mean += d.bhT[a];
+        d.HDTw[(long long)b * A + a] = mean;
         const float eps = d.eps2 ? d.eps2[(long long)b * A + a]
                                  : philox_normal(d.noise_seed, (unsigned long long)sa.step_now, (unsigned)(b * d.NI + a), 1u);
-        const float act = tanhf(d.HDT[(long long)b * A + a]) + fminf(fmaxf(eps * d.td3_sigma, -d.td3_clip), d.td3_clip);
+        const float act = tanhf(mean) + fminf(fmaxf(eps * d.td3_sigma, -d.td3_clip), d.td3_clip);
         d.a2[(long long)b * A + a] = act;
         d.XQ[(long long)(n + b) * ldq + O + a] = act;
     }
 }
 
-// y = reward_scale r + (1 - d) discount min(T1, T2)(s', a~); dL/dq_i = 2 (q_i - y) / n
+// One workgroup per batch row b: the LAST layers of Q1, Q2 on (s, a) and of their targets on (s', a~) (one output each), then
+// y = reward_scale r + (1 - d) discount min(T1, T2)(s', a~), dL/dq_i = 2 (q_i - y) / n, and the backward pass through
+// those last layers (k_g_loss's structure).
 __global__ __launch_bounds__(256) void k_g_td3_loss(GDev d, const float *__restrict__ S, SlotLayout SL) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= d.n) return;
-    const float invB = 1.0f / (float)d.n;
-    const float y = bellman_target(d.reward_scale, S[SL.off_rew + b], S[SL.off_term + b], d.discount, fminf(d.QO[2][b], d.QO[3][b]));
-    d.y[b] = y;
-    d.DQ[0][b] = 2.0f * (d.QO[0][b] - y) * invB;
-    d.DQ[1][b] = 2.0f * (d.QO[1][b] - y) * invB;
+    const int b = blockIdx.x, n = d.n, K = d.KQl;
+    __shared__ float red[4][4];
+    __shared__ float s_dq[2];
+    const float *h[4] = {d.QHl[0] + (long long)b * K, d.QHl[1] + (long long)b * K, d.THl[0] + (long long)b * K, d.THl[1] + (long long)b * K};
+    const float *w[4] = {d.Wl[0], d.Wl[1], d.Wl[2], d.Wl[3]};
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float p_rew = 0.f, p_term = 0.f, p_b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x == 0) {
+        p_rew = S[SL.off_rew + b]; p_term = S[SL.off_term + b];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p_b[q] = d.bl[q][0];
+    }
+#pragma unroll 4
+    for (int k = threadIdx.x; k < K; k += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(h[q][k], w[q][k], acc[q]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_xor(acc[q], o);
+        if (lane == 0) red[wave][q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((red[0][q] + red[1][q]) + (red[2][q] + red[3][q])) + p_b[q];      // fixed order
+        const float invB = 1.0f / (float)n;
+        const float y = bellman_target(d.reward_scale, p_rew, p_term, d.discount, fminf(v[2], v[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d.QOw[q][b] = v[q];
+        d.y[b] = y;
+        const float g0 = 2.0f * (v[0] - y) * invB, g1 = 2.0f * (v[1] - y) * invB;
+        d.DQ[0][b] = g0; d.DQ[1][b] = g1;
+        s_dq[0] = g0; s_dq[1] = g1;
+    }
+    __syncthreads();
+    float *o[2] = {d.dQZl[0] + (long long)b * K, d.dQZl[1] + (long long)b * K};
+    for (int k = threadIdx.x; k < K; k += 256) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) o[q][k] = (h[q][k] > 0.f) ? s_dq[q] * w[q][k] : 0.f;
+    }
 }
 
-// actor pass: Q1's input rows [obs | tanh(policy(s))]; the loss -mean Q1 has the gradient -1/n on every row
+// actor pass: the online policy's head layer (A outputs) and Q1's input rows [obs | tanh(policy(s))]; the loss -mean Q1 has the
+// gradient -1/n on every row
 __global__ __launch_bounds__(256) void k_g_td3_ahead(GDev d, const float *__restrict__ S, SlotLayout SL) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
+    __shared__ float part[GRW][16][33];
+    __shared__ float xs[GRW][GCK];
+    __shared__ float ws[32][GCK + 1];
     for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < n * O; e += (int)(gridDim.x * 256)) {
         const int b = e / O, k = e - b * O;
         d.XA[(long long)b * ldq + k] = S[SL.off_obs + (long long)b * O + k];
     }
-    const int b = blockIdx.x * 16 + (threadIdx.x >> 4), a = threadIdx.x & 15;
-    if (b < n && a < A) {
-        const float act = tanhf(d.HDP[(long long)b * A + a]);
+    const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, rr = threadIdx.x >> 4, b = r0 + rr;
+    small_layer_rows(d.PHl, d.KPl, d.Wh, A, false, r0, n, part, xs, ws);
+    if (rr < GRW && b < n && a < A) {
+        float mean = part[rr][0][a];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) mean += part[rr][q][a];                                  // fixed order
+        mean += d.bh[a];
+        d.HDPw[(long long)b * A + a] = mean;
+        const float act = tanhf(mean);
         d.pa[(long long)b * A + a] = act;
         d.XA[(long long)b * ldq + O + a] = act;
         if (a == 0) d.DQA[b] = -1.0f / (float)n;
     }
 }
 
-// dL/d(pre-tanh) = dL/da (1 - a^2)
+// actor pass: Q1's last layer on (s, pi(s)) (one output per row: Q1(s, pi(s)), the actor loss's statistic) and the backward pass
+// through it for the loss -mean Q1: dL/dh = -1/n w where h > 0.  One workgroup per batch row.
+__global__ __launch_bounds__(256) void k_g_td3_qa(GDev d, int backward) {
+    const int b = blockIdx.x, n = d.n, K = d.KQl;
+    __shared__ float red[4];
+    const float *h = d.AHl + (long long)b * K, *w = d.Wl[0];
+    float acc = 0.f;
+#pragma unroll 4
+    for (int k = threadIdx.x; k < K; k += 256) acc = fmaf(h[k], w[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) d.QAw[b] = ((red[0] + red[1]) + (red[2] + red[3])) + d.bl[0][0];      // fixed order
+    if (!backward) return;
+    const float g = -1.0f / (float)n;
+    float *o = d.dAZl + (long long)b * K;
+    for (int k = threadIdx.x; k < K; k += 256) o[k] = (h[k] > 0.f) ? g * w[k] : 0.f;
+}
+
+// actor pass, one workgroup per GRW batch rows: dL/da through the action columns of Q1's first layer, dL/d(pre-tanh) = dL/da (1 - a^2),
+// and the backward pass through the policy's head layer (k_g_polgrad's structure with one critic and A head rows)
 __global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)d.n * d.A) return;
-    const float act = d.pa[e];
-    d.DHP[e] = d.DAa[e] * (1.0f - act * act);
+    const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq, t = threadIdx.x;
+    __shared__ float part[GRW][16][33];
+    __shared__ float dhd[GRW][16];
+    __shared__ float gs[GRW][GCK];
+    __shared__ float was[GCK][17];
+    const int a = t & 15, hg = t >> 4;
+    const int K = d.KPl;
+    float wv[16], hm[GRW];
+    {
+        const int k = t < K ? t : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wv[j] = (j < A) ? d.Wh[(long long)j * K + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k];
+    }
+    const int rr = t >> 4;
+    const bool head_thread = rr < GRW && b0 + rr < n && a < A;
+    float p_act = 0.f;
+    if (head_thread) p_act = d.pa[(long long)(b0 + rr) * A + a];
+    {
+        float s0[GRW], rg[GRW], rwa[16];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) s0[q] = 0.f;
+        auto fetch = [&](int h0) {
+            const int hh = h0 + t;
+            const bool in = hh < H0;
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) rg[q] = in ? d.dAZ0[(long long)(b0 + q < n ? b0 + q : b0) * H0 + hh] : 0.f;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {                  // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
+                const int e = t + 256 * m, hl = e / A, j = e - hl * A;
+                rwa[m] = (m < A && h0 + hl < H0) ? d.W1q[0][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
+            }
+        };
+        fetch(0);
+        for (int h0 = 0; h0 < H0; h0 += GCK) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) gs[q][t] = rg[q];
+#pragma unroll
+            for (int m = 0; m < 16; ++m)
+                if (m < A) {
+                    const int e = t + 256 * m, hl = e / A, j = e - hl * A;
+                    was[hl][j] = rwa[m];
+                }
+            __syncthreads();
+            if (h0 + GCK < H0) fetch(h0 + GCK);
+#pragma unroll
+            for (int i = 0; i < GCK / 16; ++i) {
+                const int hl = hg + 16 * i;
+                const float w0v = was[hl][a];
+#pragma unroll
+                for (int q = 0; q < GRW; ++q) s0[q] = fmaf(gs[q][hl], w0v, s0[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) part[q][hg][a] = s0[q];
+    }
+    if (t < GRW * 16) dhd[t >> 4][t & 15] = 0.f;
+    __syncthreads();
+    if (head_thread) {
+        float da = part[rr][0][a];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) da += part[rr][q][a];                                    // fixed order
+        const long long e = (long long)(b0 + rr) * A + a;
+        d.DAaw[e] = da;
+        const float g = da * (1.0f - p_act * p_act);
+        d.DHP[e] = g;
+        dhd[rr][a] = g;
+    }
+    __syncthreads();
+    for (int k = t; k < K; k += 256) {
+        float wc[16], hc[GRW];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) wc[j] = wv[j];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) hc[q] = hm[q];
+        if (k + 256 < K) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wv[j] = (j < A) ? d.Wh[(long long)j * K + k + 256] : 0.f;
+#pragma unroll
+            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k + 256];
+        }
+        float sacc[GRW];
+#pragma unroll
+        for (int q = 0; q < GRW; ++q) sacc[q] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < A) {
+#pragma unroll
+                for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wc[j], sacc[q]);
+            }
+#pragma unroll
+        for (int q = 0; q < GRW; ++q)
+            if (b0 + q < n) d.dPZl[(long long)(b0 + q) * K + k] = (hc[q] > 0.f) ? sacc[q] : 0.f;
+    }
 }
 
 // TD3's statistics in the slots of the SAC vector (sac_hip.h): sa.pad bit 0 = the critic part (every step), bit 1 = the policy

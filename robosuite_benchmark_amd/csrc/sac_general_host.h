@@ -12,7 +12,7 @@ struct GenNet {
 };
 constexpr int GEN_MAX_JOBS = 16 * gen::GMAXJ;
 struct GenStage { int kind = 0, mode = 0; size_t base = 0; gen::GemmStage gs{}; };   // mode: 0 forward, 1 backward, 2 weight gradients   // kind 0: a k_g_gemm launch; else see launch
-enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_DIAG, GS_TD3_HEAD, GS_TD3_LOSS, GS_TD3_AHEAD, GS_TD3_POLGRAD };
+enum { GS_GEMM = 0, GS_HEAD, GS_LOSS, GS_POLGRAD, GS_DIAG, GS_TD3_HEAD, GS_TD3_LOSS, GS_TD3_AHEAD, GS_TD3_POLGRAD, GS_TD3_QA };
 
 struct sac_general {
     int n = 0, O = 0, A = 0, Lp = 0, Lq = 0;
@@ -378,20 +378,27 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
     const SlotLayout &XL = t->ext_layout;
     auto Wp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offW; };
     auto Bp = [&](int net, int l) { return g->net[net].P + g->net[net].L[l].offB; };
-    // a policy (net) forward on the slot's rows at `off`: trunk into PHx, head pre-activations into HD
-    auto policy_fwd = [&](int net, long long off, float **PHx, float *HD) {
-        for (int l = 0; l <= Lp; ++l) {
+    // a policy (net) forward on the slot's rows at `off`: the trunk into PHx (the head layer -- A outputs -- rides in the kernel
+    // behind it, like every layer of a handful of outputs: see gen_build)
+    auto policy_fwd = [&](int net, long long off, float **PHx) {
+        for (int l = 0; l < Lp; ++l) {
             const GenLayer &L = g->net[net].L[l];
-            gen::GemmJob J = gen_fwd(l == 0 ? nullptr : PHx[l - 1], n, Wp(net, l), Bp(net, l), L.N, L.K, l < Lp ? PHx[l] : HD, l < Lp);
+            gen::GemmJob J = gen_fwd(l == 0 ? nullptr : PHx[l - 1], n, Wp(net, l), Bp(net, l), L.N, L.K, PHx[l], 1);
             if (l == 0) { J.a_slot = 1; J.a_off = off; }
             pl.one(0, J);
         }
     };
+    d.KPl = hp[Lp - 1]; d.KQl = hq[Lq - 1]; d.HQ0 = hq[0];
+    d.PHTl = PHT[Lp - 1]; d.WhT = Wp(5, Lp); d.bhT = Bp(5, Lp); d.HDTw = HDT;
+    d.PHl = PHP[Lp - 1]; d.Wh = Wp(0, Lp); d.bh = Bp(0, Lp); d.HDPw = HDP; d.dPZl = dPZ[Lp - 1];
+    for (int k = 0; k < 2; ++k) { d.QHl[k] = QH[k][Lq - 1]; d.THl[k] = TH[k][Lq - 1]; d.dQZl[k] = dQZ[k][Lq - 1]; }
+    for (int k = 0; k < 4; ++k) { d.Wl[k] = Wp(1 + k, Lq); d.bl[k] = Bp(1 + k, Lq); d.QOw[k] = QO[k]; }
+    d.AHl = AH[Lq - 1]; d.dAZl = dAZ[Lq - 1]; d.dAZ0 = dAZ[0]; d.W1q[0] = Wp(1, 0); d.QAw = QA; d.DAaw = DAa;
     // ---- the critic pass ----
     pl.list = &g->td3_critic;
-    policy_fwd(5, XL.off_nobs, PHT, HDT);
+    policy_fwd(5, XL.off_nobs, PHT);
     pl.plain(GS_TD3_HEAD);
-    for (int l = 0; l <= Lq; ++l) {                      // Q1, Q2 on (s, a), their targets on (s', a~)
+    for (int l = 0; l < Lq; ++l) {                       // Q1, Q2 on (s, a), their targets on (s', a~): the hidden layers
         pl.begin(0);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[l];
@@ -404,11 +411,11 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
         pl.end();
     }
     pl.plain(GS_TD3_LOSS);
-    for (int j = Lq; j >= 1; --j) {
+    for (int j = Lq - 1; j >= 1; --j) {
         pl.begin(1);
         for (int k = 0; k < 2; ++k) {
             const GenLayer &L = g->net[1 + k].L[j];
-            pl.add(gen_bwd(j == Lq ? d.DQ[k] : dQZ[k][j], n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
+            pl.add(gen_bwd(dQZ[k][j], n, L.N, Wp(1 + k, j), L.K, 0, L.K, dQZ[k][j - 1], L.K, QH[k][j - 1], L.K));
         }
         pl.end();
     }
@@ -423,25 +430,23 @@ int gen_build_td3(sac_trainer *t, const td3_config_t *c, const int *hp, int np_,
     // ---- the actor pass (and its forward half for statistics steps) ----
     for (int full = 1; full >= 0; --full) {
         pl.list = full ? &g->td3_actor : &g->td3_stats;
-        policy_fwd(0, XL.off_obs, PHP, HDP);
+        policy_fwd(0, XL.off_obs, PHP);
         pl.plain(GS_TD3_AHEAD);
-        for (int l = 0; l <= Lq; ++l) {                  // Q1(s, policy(s)) through the updated qf1
+        for (int l = 0; l < Lq; ++l) {                   // Q1(s, policy(s)) through the updated qf1: the hidden layers
             const GenLayer &L = g->net[1].L[l];
-            pl.one(0, gen_fwd(l == 0 ? d.XA : AH[l - 1], n, Wp(1, l), Bp(1, l), L.N, L.K, l < Lq ? AH[l] : QA, l < Lq));
+            pl.one(0, gen_fwd(l == 0 ? d.XA : AH[l - 1], n, Wp(1, l), Bp(1, l), L.N, L.K, AH[l], 1));
         }
+        pl.plain(GS_TD3_QA);                             // its last layer (and, on policy steps, the backward pass through it)
+        pl.list->back().mode = full;
         if (full) {
-            for (int j = Lq; j >= 1; --j) {
+            for (int j = Lq - 1; j >= 1; --j) {
                 const GenLayer &L = g->net[1].L[j];
-                pl.one(1, gen_bwd(j == Lq ? d.DQA : dAZ[j], n, L.N, Wp(1, j), L.K, 0, L.K, dAZ[j - 1], L.K, AH[j - 1], L.K));
-            }
-            {
-                const GenLayer &L = g->net[1].L[0];
-                pl.one(1, gen_bwd(dAZ[0], n, L.N, Wp(1, 0), L.K, O, A, DAa, A, nullptr, 0));
+                pl.one(1, gen_bwd(dAZ[j], n, L.N, Wp(1, j), L.K, 0, L.K, dAZ[j - 1], L.K, AH[j - 1], L.K));
             }
             pl.plain(GS_TD3_POLGRAD);
-            for (int j = Lp; j >= 1; --j) {
+            for (int j = Lp - 1; j >= 1; --j) {
                 const GenLayer &L = g->net[0].L[j];
-                pl.one(1, gen_bwd(j == Lp ? d.DHP : dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PHP[j - 1], L.K));
+                pl.one(1, gen_bwd(dPZ[j], n, L.N, Wp(0, j), L.K, 0, L.K, dPZ[j - 1], L.K, PHP[j - 1], L.K));
             }
             pl.begin(2);
             for (int l = Lp; l >= 0; --l) {
@@ -520,10 +525,11 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
         case GS_DIAG:       // (SAC: on the steps whose diagnostics somebody reads -- the first and the last of a loop, single steps)
             if (t->algo == 1 || (sa.pad2 & 2u) || sa.loop_pos == 0) hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa);
             break;
-        case GS_TD3_HEAD: hipLaunchKernelGGL(gen::k_g_td3_head, head_grid(n, (long long)n * (2 * g->O + A)), dim3(256), 0, s, d, S, SL, sa); break;
-        case GS_TD3_LOSS: hipLaunchKernelGGL(gen::k_g_td3_loss, dim3(blocks(n, 1 << 20)), dim3(256), 0, s, d, S, SL); break;
-        case GS_TD3_AHEAD: hipLaunchKernelGGL(gen::k_g_td3_ahead, head_grid(n, (long long)n * g->O), dim3(256), 0, s, d, S, SL); break;
-        case GS_TD3_POLGRAD: hipLaunchKernelGGL(gen::k_g_td3_polgrad, dim3(blocks((long long)n * A, 1 << 20)), dim3(256), 0, s, d); break;
+        case GS_TD3_HEAD: hipLaunchKernelGGL(gen::k_g_td3_head, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa); break;
+        case GS_TD3_LOSS: hipLaunchKernelGGL(gen::k_g_td3_loss, dim3(n), dim3(256), 0, s, d, S, SL); break;
+        case GS_TD3_AHEAD: hipLaunchKernelGGL(gen::k_g_td3_ahead, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL); break;
+        case GS_TD3_QA: hipLaunchKernelGGL(gen::k_g_td3_qa, dim3(n), dim3(256), 0, s, d, st.mode); break;
+        case GS_TD3_POLGRAD: hipLaunchKernelGGL(gen::k_g_td3_polgrad, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d); break;
         }
     }
     SAC_HIP(hipGetLastError());
