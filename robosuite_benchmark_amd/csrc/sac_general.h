@@ -443,20 +443,30 @@ constexpr int GCK = 256;    // their reduction chunk: one column per thread
 // independent and coalesced, the next chunk's in flight under this chunk's arithmetic -- so a chunk costs one memory
 // latency (a loop that loaded where it multiplied, sixteen strided rows per wave-load and a latency per iteration, took
 // 12 us at 512 inputs under rocprofv3).
+// (NJ: compile-time bound of the outputs, 8 / 16 / 32 -- the unrolled per-output code is what these kernels' run time is made of)
+template <int NJ>
 __device__ __forceinline__ void small_layer_rows(const float *X, int K, const float *W, int A, bool two, int r0, int nrows,
                                                  float (*part)[16][33], float (*xs)[GCK], float (*ws)[GCK + 1]) {
     const int a = threadIdx.x & 15, kg = threadIdx.x >> 4;
     const int t = threadIdx.x, nj = two ? 2 * A : A;
-    float sm[GRW], sr[GRW], rx[GRW], rw[32];
+    float sm[GRW], sr[GRW], rx[GRW], rw[NJ];
 #pragma unroll
     for (int q = 0; q < GRW; ++q) { sm[q] = 0.f; sr[q] = 0.f; }
+    // (loads are unconditional with a clamped column -- a lane-dependent condition around a load is a branch per load, and with
+    //  64-bit index arithmetic these kernels were thousands of instructions long: one wave per SIMD executes them end to end, which
+    //  is what their 12-15 us were; the activation of a column beyond K is zeroed instead, so its weights never count.  Offsets fit
+    //  32 bits: checked at creation.)
+    int xoff[GRW];
+#pragma unroll
+    for (int q = 0; q < GRW; ++q) xoff[q] = (r0 + q < nrows ? r0 + q : r0) * K;
     auto fetch = [&](int k0) {
         const int k = k0 + t;
         const bool in = k < K;
+        const int kc = in ? k : K - 1;
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) rx[q] = in ? X[(long long)(r0 + q < nrows ? r0 + q : r0) * K + k] : 0.f;
+        for (int q = 0; q < GRW; ++q) { const float v = X[xoff[q] + kc]; rx[q] = in ? v : 0.f; }
 #pragma unroll
-        for (int j = 0; j < 32; ++j) rw[j] = (j < nj && in) ? W[(long long)j * K + k] : 0.f;
+        for (int j = 0; j < NJ; ++j) if (j < nj) rw[j] = W[j * K + kc];
     };
     fetch(0);
     for (int k0 = 0; k0 < K; k0 += GCK) {
@@ -464,7 +474,7 @@ __device__ __forceinline__ void small_layer_rows(const float *X, int K, const fl
 #pragma unroll
         for (int q = 0; q < GRW; ++q) xs[q][t] = rx[q];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) if (j < nj) ws[j][t] = rw[j];
+        for (int j = 0; j < NJ; ++j) if (j < nj) ws[j][t] = rw[j];
         __syncthreads();
         if (k0 + GCK < K) fetch(k0 + GCK);
         const float *wmr = ws[a < A ? a : 0], *wrr = ws[two ? A + (a < A ? a : 0) : 0];
@@ -485,6 +495,7 @@ __device__ __forceinline__ void small_layer_rows(const float *X, int K, const fl
     __syncthreads();
 }
 
+template <int MA>       // MA: 8 for up to eight actions, else 16
 __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     __shared__ float part[GRW][16][33];
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) void k_g_head(GDev d, const float *__restrict_
         }
     }
     const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15;
-    small_layer_rows(d.PHl, d.KPl, d.Wh, A, true, r0, 2 * n, part, xs, ws);
+    small_layer_rows<2 * MA>(d.PHl, d.KPl, d.Wh, A, true, r0, 2 * n, part, xs, ws);
     const int rr = threadIdx.x >> 4, r = r0 + rr;
     if (rr < GRW && r < 2 * n) {
         const int side = r >= n ? 1 : 0, b = r - side * n;
@@ -638,6 +649,7 @@ __global__ __launch_bounds__(256) void k_g_loss(GDev d, const float *__restrict_
 // of W1: a dot product over the first hidden layer per action), d/d(mean, log_std) of mean(alpha log_pi - min Q) through
 // a = tanh(mean + std eps), and the backward pass through the policy's head layer (2A terms per hidden unit, masked).  Three
 // launches (a matrix product with A output columns, the elementwise kernel, a matrix product with a reduction of length 2A) as one.
+template <int MA>       // MA: 8 for up to eight actions, else 16
 __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
     const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq, t = threadIdx.x;
     __shared__ float part[GRW][16][33];
@@ -650,13 +662,13 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
     // layer's weights and the relu masks of this thread's first hidden unit of the last phase, and what the sixteen
     // (row, action) threads per row need from the head kernel.
     const int K = d.KPl, nj = 2 * A;
-    float wv[32], hm[GRW];
+    float wv[2 * MA], hm[GRW];
     {
         const int k = t < K ? t : 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) wv[j] = (j < nj) ? d.Wh[(long long)j * K + k] : 0.f;
+        for (int j = 0; j < 2 * MA; ++j) wv[j] = (j < nj) ? d.Wh[j * K + k] : 0.f;
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k];
+        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(b0 + q < n ? b0 + q : b0) * K + k];
     }
     const int rr = t >> 4;
     const bool head_thread = rr < GRW && b0 + rr < n && a < A;
@@ -669,23 +681,32 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
         // (the A action columns of a chunk's GCK rows of W1 are fetched as the flat sequence (row, column): consecutive lanes read
         //  consecutive columns of a row, then the next row -- a wave-load touches ~64 / A rows.  One row per lane, the first
         //  cut, touched 64 rows per wave-load: 64 cache lines per instruction, 8 us of the kernel's 15.)
-        float s0[GRW], s1[GRW], rg[GRW][2], rwa[2][16];
+        // (unconditional loads with clamped rows, 32-bit offsets, the (row, column) of a lane's elements stepped without divisions:
+        //  see small_layer_rows -- a hidden unit beyond H0 has a zero gradient, so whatever weight is loaded for it never counts)
+        float s0[GRW], s1[GRW], rg[GRW][2], rwa[2][MA];
+        const int q256 = 256 / A, r256 = 256 - q256 * A, hl_t = t / A, j_t = t - hl_t * A;
+        const float *w0a = d.W1q[0] + d.O, *w1a = d.W1q[1] + d.O;
+        int goff[GRW];
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+        for (int q = 0; q < GRW; ++q) { s0[q] = 0.f; s1[q] = 0.f; goff[q] = (n + (b0 + q < n ? b0 + q : b0)) * H0; }
         auto fetch = [&](int h0) {
             const int hh = h0 + t;
             const bool in = hh < H0;
+            const int hc = in ? hh : H0 - 1;
 #pragma unroll
             for (int q = 0; q < GRW; ++q) {
-                const long long row = (long long)(n + (b0 + q < n ? b0 + q : b0)) * H0 + hh;
-                rg[q][0] = in ? d.dQZ0[0][row] : 0.f; rg[q][1] = in ? d.dQZ0[1][row] : 0.f;
+                const float v0 = d.dQZ0[0][goff[q] + hc], v1 = d.dQZ0[1][goff[q] + hc];
+                rg[q][0] = in ? v0 : 0.f; rg[q][1] = in ? v1 : 0.f;
             }
+            int hl = hl_t, j = j_t;                         // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {                  // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
-                const int e = t + 256 * m, hl = e / A, j = e - hl * A;
-                const bool ok = m < A && h0 + hl < H0;
-                rwa[0][m] = ok ? d.W1q[0][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
-                rwa[1][m] = ok ? d.W1q[1][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
+            for (int m = 0; m < MA; ++m) {
+                if (m < A) {
+                    const int hr = h0 + hl < H0 ? h0 + hl : H0 - 1;
+                    rwa[0][m] = w0a[hr * ldq + j]; rwa[1][m] = w1a[hr * ldq + j];
+                }
+                j += r256; hl += q256;
+                if (j >= A) { j -= A; hl += 1; }
             }
         };
         fetch(0);
@@ -693,12 +714,15 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < GRW; ++q) { gs[q][0][t] = rg[q][0]; gs[q][1][t] = rg[q][1]; }
+            {
+                int hl = hl_t, j = j_t;
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                if (m < A) {
-                    const int e = t + 256 * m, hl = e / A, j = e - hl * A;
-                    was[0][hl][j] = rwa[0][m]; was[1][hl][j] = rwa[1][m];
+                for (int m = 0; m < MA; ++m) {
+                    if (m < A) { was[0][hl][j] = rwa[0][m]; was[1][hl][j] = rwa[1][m]; }
+                    j += r256; hl += q256;
+                    if (j >= A) { j -= A; hl += 1; }
                 }
+            }
             __syncthreads();
             if (h0 + GCK < H0) fetch(h0 + GCK);
 #pragma unroll
@@ -738,22 +762,22 @@ __global__ __launch_bounds__(256) void k_g_polgrad(GDev d) {
     // backward through the head layer: a thread owns hidden unit k -- its 2A weights and GRW masks in one round of loads (the
     // first unit's came in at the start; the next unit's are requested before this one's arithmetic)
     for (int k = t; k < K; k += 256) {
-        float wc[32], hc[GRW];
+        float wc[2 * MA], hc[GRW];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) wc[j] = wv[j];
+        for (int j = 0; j < 2 * MA; ++j) wc[j] = wv[j];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) hc[q] = hm[q];
         if (k + 256 < K) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) wv[j] = (j < nj) ? d.Wh[(long long)j * K + k + 256] : 0.f;
+            for (int j = 0; j < 2 * MA; ++j) wv[j] = (j < nj) ? d.Wh[j * K + k + 256] : 0.f;
 #pragma unroll
-            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k + 256];
+            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(b0 + q < n ? b0 + q : b0) * K + k + 256];
         }
         float sacc[GRW];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) sacc[q] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32; ++j)
+        for (int j = 0; j < 2 * MA; ++j)
             if (j < nj) {
 #pragma unroll
                 for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wc[j], sacc[q]);
@@ -847,6 +871,7 @@ __device__ void diag_block(const GDev &d, const StepArg &sa) {
 // ------------------------------------------------------------------------------------------
 // critic pass: the Q nets' input rows [(s, a) ; (s', a~)], a~ = tanh(target policy(s')) + clamp(N(0,1) sigma, +-clip)
 // (the sum is NOT clipped to the action range)
+template <int MA>
 __global__ __launch_bounds__(256) void k_g_td3_head(GDev d, const float *__restrict__ S, SlotLayout SL, StepArg sa) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     __shared__ float part[GRW][16][33];
@@ -863,7 +888,7 @@ __global__ __launch_bounds__(256) void k_g_td3_head(GDev d, const float *__restr
     }
     // the target policy's head layer (A outputs) on the GRW rows of this workgroup, then thread = (row, action)
     const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, rr = threadIdx.x >> 4, b = r0 + rr;
-    small_layer_rows(d.PHTl, d.KPl, d.WhT, A, false, r0, n, part, xs, ws);
+    small_layer_rows<MA>(d.PHTl, d.KPl, d.WhT, A, false, r0, n, part, xs, ws);
     if (rr < GRW && b < n && a < A) {
         float mean = part[rr][0][a];
 #pragma unroll
@@ -930,6 +955,7 @@ __global__ __launch_bounds__(256) void k_g_td3_loss(GDev d, const float *__restr
 
 // actor pass: the online policy's head layer (A outputs) and Q1's input rows [obs | tanh(policy(s))]; the loss -mean Q1 has the
 // gradient -1/n on every row
+template <int MA>
 __global__ __launch_bounds__(256) void k_g_td3_ahead(GDev d, const float *__restrict__ S, SlotLayout SL) {
     const int n = d.n, O = d.O, A = d.A, ldq = d.ldq;
     __shared__ float part[GRW][16][33];
@@ -940,7 +966,7 @@ __global__ __launch_bounds__(256) void k_g_td3_ahead(GDev d, const float *__rest
         d.XA[(long long)b * ldq + k] = S[SL.off_obs + (long long)b * O + k];
     }
     const int r0 = blockIdx.x * GRW, a = threadIdx.x & 15, rr = threadIdx.x >> 4, b = r0 + rr;
-    small_layer_rows(d.PHl, d.KPl, d.Wh, A, false, r0, n, part, xs, ws);
+    small_layer_rows<MA>(d.PHl, d.KPl, d.Wh, A, false, r0, n, part, xs, ws);
     if (rr < GRW && b < n && a < A) {
         float mean = part[rr][0][a];
 #pragma unroll
@@ -976,6 +1002,7 @@ __global__ __launch_bounds__(256) void k_g_td3_qa(GDev d, int backward) {
 
 // actor pass, one workgroup per GRW batch rows: dL/da through the action columns of Q1's first layer, dL/d(pre-tanh) = dL/da (1 - a^2),
 // and the backward pass through the policy's head layer (k_g_polgrad's structure with one critic and A head rows)
+template <int MA>
 __global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
     const int b0 = blockIdx.x * GRW, n = d.n, A = d.A, H0 = d.HQ0, ldq = d.ldq, t = threadIdx.x;
     __shared__ float part[GRW][16][33];
@@ -984,31 +1011,37 @@ __global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
     __shared__ float was[GCK][17];
     const int a = t & 15, hg = t >> 4;
     const int K = d.KPl;
-    float wv[16], hm[GRW];
+    float wv[MA], hm[GRW];
     {
         const int k = t < K ? t : 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wv[j] = (j < A) ? d.Wh[(long long)j * K + k] : 0.f;
+        for (int j = 0; j < MA; ++j) wv[j] = (j < A) ? d.Wh[j * K + k] : 0.f;
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k];
+        for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(b0 + q < n ? b0 + q : b0) * K + k];
     }
     const int rr = t >> 4;
     const bool head_thread = rr < GRW && b0 + rr < n && a < A;
     float p_act = 0.f;
     if (head_thread) p_act = d.pa[(long long)(b0 + rr) * A + a];
     {
-        float s0[GRW], rg[GRW], rwa[16];
+        float s0[GRW], rg[GRW], rwa[MA];
+        const int q256 = 256 / A, r256 = 256 - q256 * A, hl_t = t / A, j_t = t - hl_t * A;
+        const float *w0a = d.W1q[0] + d.O;
+        int goff[GRW];
 #pragma unroll
-        for (int q = 0; q < GRW; ++q) s0[q] = 0.f;
+        for (int q = 0; q < GRW; ++q) { s0[q] = 0.f; goff[q] = (b0 + q < n ? b0 + q : b0) * H0; }
         auto fetch = [&](int h0) {
             const int hh = h0 + t;
             const bool in = hh < H0;
+            const int hc = in ? hh : H0 - 1;
 #pragma unroll
-            for (int q = 0; q < GRW; ++q) rg[q] = in ? d.dAZ0[(long long)(b0 + q < n ? b0 + q : b0) * H0 + hh] : 0.f;
+            for (int q = 0; q < GRW; ++q) { const float v = d.dAZ0[goff[q] + hc]; rg[q] = in ? v : 0.f; }
+            int hl = hl_t, j = j_t;                         // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
 #pragma unroll
-            for (int m = 0; m < 16; ++m) {                  // element e = t + 256 m of the chunk's GCK * A: (row e / A, column e % A)
-                const int e = t + 256 * m, hl = e / A, j = e - hl * A;
-                rwa[m] = (m < A && h0 + hl < H0) ? d.W1q[0][(long long)(h0 + hl) * ldq + d.O + j] : 0.f;
+            for (int m = 0; m < MA; ++m) {
+                if (m < A) rwa[m] = w0a[(h0 + hl < H0 ? h0 + hl : H0 - 1) * ldq + j];
+                j += r256; hl += q256;
+                if (j >= A) { j -= A; hl += 1; }
             }
         };
         fetch(0);
@@ -1016,12 +1049,15 @@ __global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < GRW; ++q) gs[q][t] = rg[q];
+            {
+                int hl = hl_t, j = j_t;
 #pragma unroll
-            for (int m = 0; m < 16; ++m)
-                if (m < A) {
-                    const int e = t + 256 * m, hl = e / A, j = e - hl * A;
-                    was[hl][j] = rwa[m];
+                for (int m = 0; m < MA; ++m) {
+                    if (m < A) was[hl][j] = rwa[m];
+                    j += r256; hl += q256;
+                    if (j >= A) { j -= A; hl += 1; }
                 }
+            }
             __syncthreads();
             if (h0 + GCK < H0) fetch(h0 + GCK);
 #pragma unroll
@@ -1049,22 +1085,22 @@ __global__ __launch_bounds__(256) void k_g_td3_polgrad(GDev d) {
     }
     __syncthreads();
     for (int k = t; k < K; k += 256) {
-        float wc[16], hc[GRW];
+        float wc[MA], hc[GRW];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) wc[j] = wv[j];
+        for (int j = 0; j < MA; ++j) wc[j] = wv[j];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) hc[q] = hm[q];
         if (k + 256 < K) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) wv[j] = (j < A) ? d.Wh[(long long)j * K + k + 256] : 0.f;
+            for (int j = 0; j < MA; ++j) wv[j] = (j < A) ? d.Wh[j * K + k + 256] : 0.f;
 #pragma unroll
-            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(long long)(b0 + q < n ? b0 + q : b0) * K + k + 256];
+            for (int q = 0; q < GRW; ++q) hm[q] = d.PHl[(b0 + q < n ? b0 + q : b0) * K + k + 256];
         }
         float sacc[GRW];
 #pragma unroll
         for (int q = 0; q < GRW; ++q) sacc[q] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int j = 0; j < MA; ++j)
             if (j < A) {
 #pragma unroll
                 for (int q = 0; q < GRW; ++q) sacc[q] = fmaf(dhd[q][j], wc[j], sacc[q]);

@@ -519,17 +519,26 @@ int gen_run_list(sac_trainer *t, const std::vector<GenStage> &list, const float 
             break;
         }
         // (SAC: one workgroup per row / per GRW rows -- the kernels hold the layers of a handful of outputs, see gen_build)
-        case GS_HEAD: hipLaunchKernelGGL(gen::k_g_head, dim3((2 * n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa); break;
+        case GS_HEAD: if (A <= 8) hipLaunchKernelGGL(gen::k_g_head<8>, dim3((2 * n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa);
+            else hipLaunchKernelGGL(gen::k_g_head<16>, dim3((2 * n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa); break;
         case GS_LOSS: hipLaunchKernelGGL(gen::k_g_loss, dim3(n), dim3(256), 0, s, d, S, SL); break;
-        case GS_POLGRAD: hipLaunchKernelGGL(gen::k_g_polgrad, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d); break;
+        case GS_POLGRAD: if (A <= 8) hipLaunchKernelGGL(gen::k_g_polgrad<8>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d);
+            else hipLaunchKernelGGL(gen::k_g_polgrad<16>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d);
+            break;
         case GS_DIAG:       // (SAC: on the steps whose diagnostics somebody reads -- the first and the last of a loop, single steps)
             if (t->algo == 1 || (sa.pad2 & 2u) || sa.loop_pos == 0) hipLaunchKernelGGL(gen::k_g_diag, dim3(1), dim3(256), 0, s, d, sa);
             break;
-        case GS_TD3_HEAD: hipLaunchKernelGGL(gen::k_g_td3_head, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa); break;
+        case GS_TD3_HEAD: if (A <= 8) hipLaunchKernelGGL(gen::k_g_td3_head<8>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa);
+            else hipLaunchKernelGGL(gen::k_g_td3_head<16>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL, sa);
+            break;
         case GS_TD3_LOSS: hipLaunchKernelGGL(gen::k_g_td3_loss, dim3(n), dim3(256), 0, s, d, S, SL); break;
-        case GS_TD3_AHEAD: hipLaunchKernelGGL(gen::k_g_td3_ahead, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL); break;
+        case GS_TD3_AHEAD: if (A <= 8) hipLaunchKernelGGL(gen::k_g_td3_ahead<8>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL);
+            else hipLaunchKernelGGL(gen::k_g_td3_ahead<16>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d, S, SL);
+            break;
         case GS_TD3_QA: hipLaunchKernelGGL(gen::k_g_td3_qa, dim3(n), dim3(256), 0, s, d, st.mode); break;
-        case GS_TD3_POLGRAD: hipLaunchKernelGGL(gen::k_g_td3_polgrad, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d); break;
+        case GS_TD3_POLGRAD: if (A <= 8) hipLaunchKernelGGL(gen::k_g_td3_polgrad<8>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d);
+            else hipLaunchKernelGGL(gen::k_g_td3_polgrad<16>, dim3((n + gen::GRW - 1) / gen::GRW), dim3(256), 0, s, d);
+            break;
         }
     }
     SAC_HIP(hipGetLastError());
