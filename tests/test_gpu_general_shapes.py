@@ -210,6 +210,28 @@ def test_td3_steps_against_the_oracle(hidden, task, B):
     assert got["scalars"][0] == 3 and got["scalars"][3] == got["scalars"][4] == 5       # policy steps 0, 2, 4
 
 
+@pytest.mark.parametrize("hidden,O,A,B", [((33,), 9, 16, 5), ((300, 2), 4, 1, 3), ((7, 700), 120, 9, 18)])
+def test_td3_extreme_shapes_against_the_oracle(hidden, O, A, B):
+    """TD3's small-layer kernels at their corners: sixteen actions and one, batches that are no multiple of their four rows per
+    workgroup, a last hidden layer wider than one reduction chunk and one of two units -- three steps against the oracle."""
+    from tests.helpers import make_td3_pair
+    from tests.test_gpu_td3 import batch_and_noise as td3_batch, check_diag as td3_check
+    oracle, hip = make_td3_pair(O, A, B, seed=5, hidden=hidden, policy_and_target_update_period=2)
+    assert hip.fused_mode() == 3
+    for s_ in range(3):
+        nb, eps = td3_batch(B, O, A, seed=900 + s_)
+        want = oracle.step(nb["observations"], nb["actions"], nb["rewards"], nb["terminals"], nb["next_observations"], eps)
+        diag = hip.train(nb, eps=eps)
+        if s_ == 0:
+            td3_check(diag, want)
+            L = oracle.last
+            for name, ref in (("a_next", L["noisy"]), ("a_new", L["pa"])):
+                assert scale_err(hip.debug_fetch(name, B * A), ref.detach().numpy().ravel()) < 2e-5, name
+            for g_ in ("g_qf1", "g_qf2", "g_policy"):
+                assert scale_err(hip.debug_fetch(g_, L[g_].size), L[g_]) < 5e-5, g_
+    assert np.isfinite(np.asarray(diag, dtype=np.float64)[:20]).all()
+
+
 def test_td3_general_loop_stepwise_and_the_fused_kernels(monkeypatch):
     """The TD3 general step behind the loop and the stepwise interface (bitwise one trajectory), and against the fused
     kernels on [256, 256] (SAC_GENERAL=1), same device noise stream: within fp32 round-off."""
